@@ -1,0 +1,214 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference, never shipped to the
+GPU box). The reference is imported, not copied: we load our seeded synthetic
+state dict into its modules with load_state_dict(strict=True) — which also
+proves our key/shape inventory equals the reference's — run its forward /
+infer_video_depth, and save inputs + outputs as data.
+
+Harness shims (none of them replaces arithmetic on the pinned path):
+  easydict     -> dict subclass (only used as **kwargs, dpt_temporal.py:35-48)
+  torchvision  -> transforms.Compose = call each transform in turn
+  cv2          -> INTER_* constants + resize() that asserts identity size
+`VideoDepthAnything.__init__` is skipped (video_depth.py:60 is a network fetch);
+the object is assembled as `pretrained = DINOv2(encoder)`, `head = DPTHeadTemporal(...)`,
+which is what the commented upstream constructor at :59 and metric_depth/...:54 do.
+
+Usage:  python oracle/gen_golden.py [--metric]
+"""
+import argparse
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def install_shims():
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        pass
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    tvt.Compose = Compose
+    tv.transforms = tvt
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tvt
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.INTER_NEAREST = 2, 3, 0
+
+    def resize(img, size, interpolation=None):
+        assert (img.shape[1], img.shape[0]) == tuple(size), "golden generator only covers identity resize"
+        return img
+
+    cv2.resize = resize
+    sys.modules["cv2"] = cv2
+
+
+def build_reference(cfg, sd, ref_root):
+    sys.path.insert(0, ref_root)
+    import torch.nn as nn
+    from video_depth_anything import video_depth as vd
+    from video_depth_anything.dinov2 import DINOv2, DinoVisionTransformer
+    from video_depth_anything.dinov2_layers import MemEffAttention, NestedTensorBlock as Block
+    from video_depth_anything.dpt_temporal import DPTHeadTemporal
+
+    m = vd.VideoDepthAnything.__new__(vd.VideoDepthAnything)
+    nn.Module.__init__(m)
+    m.intermediate_layer_idx = {cfg.name: list(cfg.taps)}
+    m.encoder = cfg.name
+    if cfg.name in ("vits", "vitl"):
+        m.pretrained = DINOv2(model_name=cfg.name)
+    else:
+        m.pretrained = DinoVisionTransformer(
+            img_size=518, patch_size=14, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+            mlp_ratio=4, block_fn=partial(Block, attn_class=MemEffAttention), init_values=1.0, ffn_layer="mlp",
+            block_chunks=0, num_register_tokens=0, interpolate_antialias=False, interpolate_offset=0.1)
+    m.head = DPTHeadTemporal(m.pretrained.embed_dim, cfg.features, False, out_channels=list(cfg.out_channels),
+                             use_clstoken=False, num_frames=cfg.num_frames, pe="ape")
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def sd_checksum(sd):
+    return np.array([float(v.double().abs().sum()) for v in sd.values()], dtype=np.float64)
+
+
+def capture_stages(model):
+    """Forward hooks on the head's submodules, in the order dpt_temporal.py calls them."""
+    store = {}
+    hs = []
+
+    def hook(name):
+        def f(mod, inp, out):
+            store[name] = out.detach().clone()
+        return f
+
+    h = model.head
+    hs.append(h.resize_layers[0].register_forward_hook(hook("layer_1")))
+    hs.append(h.resize_layers[1].register_forward_hook(hook("layer_2")))
+    for i, n in enumerate(("layer_3", "layer_4", "path_4", "path_3")):
+        hs.append(h.motion_modules[i].register_forward_hook(hook(n + "_bcthw")))
+    hs.append(h.scratch.refinenet2.register_forward_hook(hook("path_2")))
+    hs.append(h.scratch.refinenet1.register_forward_hook(hook("path_1")))
+    return store, hs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--metric", action="store_true", help="generate the metric_depth stitch golden instead")
+    args = ap.parse_args()
+    install_shims()
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.weights import synthetic_state_dict
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+
+    if args.metric:
+        # metric_depth/ carries its own copy of the package; run it in a process of its own.
+        cfg = get_config("tiny")
+        sd = synthetic_state_dict(cfg, seed=6)
+        model = build_reference(cfg, sd, "/root/reference/metric_depth")
+        rng = np.random.default_rng(13)
+        frames = rng.integers(0, 256, (50, 42, 56, 3), dtype=np.uint8)
+        depths, _ = model.infer_video_depth(frames, 24, input_size=42, device="cpu", fp32=True)
+        np.savez_compressed(os.path.join(OUT, "tiny_metric_video.npz"), frames=frames, depths=depths.astype(np.float32),
+                            sd_seed=6, sd_checksum=sd_checksum(sd), input_size=42)
+        print("tiny_metric_video", depths.shape, float(depths.mean()))
+        return
+
+    # ---- 1. tiny config, non-square input, every stage tapped --------------------
+    cfg = get_config("tiny")
+    sd = synthetic_state_dict(cfg, seed=1)
+    model = build_reference(cfg, sd, "/root/reference")
+    g = torch.Generator().manual_seed(101)
+    x = torch.randn(1, 4, 3, 42, 56, generator=g)
+    store, hooks = capture_stages(model)
+    with torch.no_grad():
+        taps = model.pretrained.get_intermediate_layers(x.flatten(0, 1), list(cfg.taps), return_class_token=True)
+        depth = model.forward(x)
+    for h in hooks:
+        h.remove()
+    out = {"x": x.numpy(), "depth": depth.numpy(), "sd_seed": 1, "sd_checksum": sd_checksum(sd)}
+    for i, (t, c) in enumerate(taps):
+        out[f"tap{i}"] = t.numpy()
+    for k, v in store.items():
+        if k.endswith("_bcthw"):                        # [B,C,T,h,w] -> frame-major [(B T),C,h,w]
+            v = v.permute(0, 2, 1, 3, 4).flatten(0, 1)
+            k = k[:-6]
+        out[k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_forward.npz"), **out)
+    print("tiny_forward", depth.shape, float(depth.mean()), {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+    # ---- 2. tiny config: infer_video_depth, 3 windows ----------------------------
+    sd = synthetic_state_dict(cfg, seed=2)
+    model.load_state_dict(sd, strict=True)
+    rng = np.random.default_rng(12)
+    frames = rng.integers(0, 256, (50, 42, 56, 3), dtype=np.uint8)
+    depths, fps = model.infer_video_depth(frames, 24, input_size=42, device="cpu", fp32=True)
+    np.savez_compressed(os.path.join(OUT, "tiny_video.npz"), frames=frames, depths=depths.astype(np.float32),
+                        sd_seed=2, sd_checksum=sd_checksum(sd), input_size=42)
+    print("tiny_video", depths.shape, depths.dtype, float(depths.mean()), fps)
+
+    # ---- 3. real ViT-S, small non-square clip ------------------------------------
+    cfg = get_config("vits")
+    sd = synthetic_state_dict(cfg, seed=0)
+    model = build_reference(cfg, sd, "/root/reference")
+    g = torch.Generator().manual_seed(102)
+    x = torch.randn(1, 3, 3, 56, 70, generator=g)
+    with torch.no_grad():
+        depth = model.forward(x)
+    np.savez_compressed(os.path.join(OUT, "vits_forward.npz"), x=x.numpy(), depth=depth.numpy(),
+                        sd_seed=0, sd_checksum=sd_checksum(sd))
+    print("vits_forward", depth.shape, float(depth.mean()))
+
+    # ---- 4. real ViT-S, one 518x518 frame (stored pos_embed path, 1370 tokens) ----
+    g = torch.Generator().manual_seed(103)
+    x = torch.randn(1, 1, 3, 518, 518, generator=g)
+    with torch.no_grad():
+        depth = model.forward(x)
+    d = depth.numpy()
+    np.savez_compressed(os.path.join(OUT, "vits_518.npz"), x_seed=103, depth_sub=d[..., ::7, ::7],
+                        depth_mean=float(d.mean()), depth_absmax=float(np.abs(d).max()),
+                        row_sums=d.sum(axis=-1).astype(np.float64), sd_seed=0, sd_checksum=sd_checksum(sd))
+    print("vits_518", depth.shape, float(depth.mean()))
+
+    # ---- 5. stitcher maths directly (utils/util.py) -------------------------------
+    from utils.util import compute_scale_and_shift, get_interpolate_frames
+    rng = np.random.default_rng(14)
+    pred = rng.random((2 * 30, 40), dtype=np.float32) * 5
+    targ = (pred * 1.7 + 0.3 + rng.normal(0, 0.05, pred.shape)).astype(np.float32)
+    s, t = compute_scale_and_shift(pred, targ, np.ones_like(targ) == 1)
+    pre = [rng.random((6, 5), dtype=np.float32) for _ in range(8)]
+    post = [rng.random((6, 5), dtype=np.float32) for _ in range(8)]
+    mix = get_interpolate_frames(pre, post)
+    np.savez_compressed(os.path.join(OUT, "stitch_math.npz"), pred=pred, targ=targ, scale=np.float64(s), shift=np.float64(t),
+                        pre=np.stack(pre), post=np.stack(post), mix=np.stack(mix))
+    print("stitch_math", s, t)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,91 @@
+"""Pins oracle/vda_oracle.py to outputs of the reference's own modules
+(fixtures written by oracle/gen_golden.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vda_oracle as O
+from video_depth_anything_amd.config import get_config
+from video_depth_anything_amd.weights import synthetic_state_dict
+
+RTOL = 1e-5   # restatement must match fixtures to <= 1e-5 rel
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def seeded_sd(cfg, z):
+    sd = synthetic_state_dict(cfg, seed=int(z["sd_seed"]))
+    chk = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    np.testing.assert_allclose(chk, z["sd_checksum"], rtol=1e-12, err_msg="seeded state dict drifted from the fixture's")
+    return sd
+
+
+def test_tiny_forward_every_stage(golden_dir):
+    z = load(golden_dir, "tiny_forward.npz")
+    cfg = get_config("tiny")
+    sd = seeded_sd(cfg, z)
+    stages = {}
+    with torch.no_grad():
+        d = O.forward(sd, cfg, torch.from_numpy(z["x"]), stages)
+    for i in range(4):
+        assert rel_err(stages["taps"][i].numpy(), z[f"tap{i}"]) < RTOL, f"tap{i}"
+    for k in ("layer_1", "layer_2", "layer_3", "layer_4", "path_4", "path_3", "path_2", "path_1"):
+        assert rel_err(stages[k].numpy(), z[k]) < RTOL, k
+    assert rel_err(d.numpy(), z["depth"]) < RTOL
+
+
+def test_vits_forward_nonsquare(golden_dir):
+    z = load(golden_dir, "vits_forward.npz")
+    cfg = get_config("vits")
+    sd = seeded_sd(cfg, z)
+    with torch.no_grad():
+        d = O.forward(sd, cfg, torch.from_numpy(z["x"]))
+    assert rel_err(d.numpy(), z["depth"]) < RTOL
+
+
+def test_vits_518_stored_pos_embed(golden_dir):
+    z = load(golden_dir, "vits_518.npz")
+    cfg = get_config("vits")
+    sd = seeded_sd(cfg, z)
+    x = torch.randn(1, 1, 3, 518, 518, generator=torch.Generator().manual_seed(int(z["x_seed"])))
+    with torch.no_grad():
+        d = O.forward(sd, cfg, x).numpy()
+    assert rel_err(d[..., ::7, ::7], z["depth_sub"]) < RTOL
+    assert rel_err(d.sum(axis=-1), z["row_sums"]) < RTOL
+    assert abs(float(d.mean()) - float(z["depth_mean"])) < RTOL * float(z["depth_absmax"])
+
+
+@pytest.mark.parametrize("name,metric", [("tiny_video.npz", False), ("tiny_metric_video.npz", True)])
+def test_infer_video_depth(golden_dir, name, metric):
+    z = load(golden_dir, name)
+    cfg = get_config("tiny")
+    sd = seeded_sd(cfg, z)
+    depths, fps = O.infer_video_depth(sd, cfg, z["frames"], 24, input_size=int(z["input_size"]), metric=metric)
+    assert depths.shape == z["depths"].shape and depths.dtype == np.float32 and fps == 24
+    assert (z["depths"] > 0).mean() > 0.2, "fixture too sparse to be a meaningful check"
+    assert rel_err(depths, z["depths"]) < 5e-5   # alignment lstsq amplifies fp32 noise slightly
+
+
+def test_stitch_math(golden_dir):
+    z = load(golden_dir, "stitch_math.npz")
+    s, t = O.compute_scale_and_shift(z["pred"], z["targ"])
+    assert s == pytest.approx(float(z["scale"]), rel=1e-6) and t == pytest.approx(float(z["shift"]), rel=1e-6)
+    mix = O.interpolate_frames(list(z["pre"]), list(z["post"]))
+    np.testing.assert_array_equal(np.stack(mix), z["mix"])
+
+
+def test_window_plan_counts():
+    # n=32 -> 2 windows; n=1024 -> 47 windows, 20 padded frames
+    assert O.window_plan(32) == (22, [0, 22])
+    a, s = O.window_plan(1024)
+    assert (a, len(s)) == (20, 47)
