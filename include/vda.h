@@ -1,0 +1,136 @@
+/*
+ * vda.h — C ABI of libvda_hip.so, the MI355X (gfx950) kernel library behind
+ * VideoDepthAnything.forward / infer_video_depth.
+ *
+ * The reference has no FFI boundary: it is pure Python/PyTorch and every entry
+ * point below replaces an ATen / xformers op site on its hot path
+ * (SURVEY.md §2.2, K1-K20). The reference call site each one stands in for is
+ * cited per function, paths relative to the reference's video_depth_anything/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    the name says host; no torch types, no ownership transfer;
+ *  - every function enqueues on `stream` (a hipStream_t passed as void*) and
+ *    returns immediately: 0 = ok, non-zero = refused (bad shape/alignment; the
+ *    text is available from vda_last_error()); nothing is launched on refusal;
+ *  - activations are fp16 ("h"), token-major / NHWC; accumulation is fp32;
+ *  - not thread-safe per stream; no allocation, no synchronisation inside
+ *    (graph-capturable).
+ */
+#ifndef VDA_H
+#define VDA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vda_stream_t;
+
+const char* vda_last_error(void);
+int vda_abi_version(void);
+
+/* ---------------------------------------------------------------- GEMM / conv
+ * out = epilogue( A[M,K] * W[N,K]^T ), fp16 operands, fp32 accumulate (MFMA).
+ * Replaces nn.Linear / 1x1 Conv2d / 3x3 Conv2d / ConvTranspose2d(k==stride):
+ *   dinov2_layers/attention.py:51,60   dinov2_layers/mlp.py:36-40
+ *   dinov2_layers/patch_embed.py:76    dpt.py:60-90,117-121   util/blocks.py:20-32,79-84,160
+ *   motion_module/motion_module.py:113,120,242-250,290   motion_module/attention.py:333,383
+ */
+enum vda_a_mode {
+    VDA_A_DENSE = 0,      /* A row m at A + m*lda (fp16) */
+    VDA_A_CONV3X3 = 1     /* implicit GEMM: A row m = output pixel (b,oy,ox), K = (ky,kx,ci) over an NHWC fp16 input, pad 1 */
+};
+
+enum vda_epilogue {
+    VDA_EPI_BIAS_F16 = 0,        /* out_h[m,n] = acc + bias[n]                                   */
+    VDA_EPI_BIAS_GELU_F16 = 1,   /* out_h = gelu_erf(acc + bias)                 mlp.py:36-37    */
+    VDA_EPI_BIAS_RELU_F16 = 2,   /* out_h = relu(acc + bias)                     blocks.py:79-83 */
+    VDA_EPI_SCALE_RES_F32 = 3,   /* out_f[m,n] = res_f[m,n] + gamma[n]*(acc + bias[n])  block.py:105-106, layer_scale.py:28 (gamma NULL = 1) */
+    VDA_EPI_RES_F16 = 4,         /* out_h = acc + bias + res_h[m,n] (+ res2_h[m,n])  blocks.py:91,145; motion_module.py:123 */
+    VDA_EPI_GEGLU_F16 = 5,       /* W rows interleaved [16 value | 16 gate]: out_h[m, n/2] = (acc_v+b_v) * gelu(acc_g+b_g)  attention.py:383-384 */
+    VDA_EPI_PATCH_F32 = 6,       /* out_f[(m/P)*(P+1) + 1 + m%P, n] = acc + bias[n] + pos[(1 + m%P)*N + n]   dinov2.py:218-219 */
+    VDA_EPI_CONVT_F16 = 7,       /* W rows ordered (ky,kx,co): pixel-shuffle scatter of a k==stride ConvTranspose2d  dpt.py:71-82 */
+    VDA_EPI_BIAS_F32 = 8         /* out_f[m,n] = acc + bias[n] */
+};
+
+typedef struct vda_gemm_args {
+    const void* A;          /* fp16: dense [M,lda] or NHWC input [B,H,W,Cin] */
+    const void* W;          /* fp16 [N,K], K contiguous */
+    const float* bias;      /* [N] or NULL */
+    void* out;
+    const void* res;        /* residual (type per epilogue) or NULL */
+    const void* res2;       /* second fp16 residual for VDA_EPI_RES_F16 or NULL */
+    const float* gamma;     /* [N] LayerScale or NULL */
+    const float* pos;       /* VDA_EPI_PATCH_F32: pos-embed [(P+1), N] */
+    const void* zero_page;  /* >= 256 B of zeros (conv padding source) */
+    int32_t M, N, K;
+    int32_t lda, ldc;       /* in elements */
+    int32_t a_mode, epilogue;
+    int32_t relu_in;        /* apply relu to A elements on load (blocks.py:78) */
+    /* VDA_A_CONV3X3 */
+    int32_t cB, cH, cW, cCin, cHo, cWo, cStride;
+    /* VDA_EPI_PATCH_F32: P patches per frame. VDA_EPI_CONVT_F16: k, input h, w, Cout */
+    int32_t P, tK, tH, tW, tCout;
+} vda_gemm_args;
+
+int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
+
+/* ---------------------------------------------------------------- norms
+ * LayerNorm over the last dim, fp32 statistics (dinov2.py:95,310; block.py:56,68;
+ * motion_module.py:155,161,166). in: fp32 [rows, D]; out: fp16.
+ *  group/skip: when group > 0, row r with r % group < skip is dropped and the
+ *  output is compacted (cls token removal for the taps, dpt_temporal.py:61).
+ *  pe/pe_rows_per_step: when pe != NULL, out += pe[(r / pe_rows_per_step) % pe_steps, :]
+ *  (temporal sinusoidal PE added to the normed input, motion_module.py:235).
+ */
+int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const float* b, float eps,
+                          int rows, int D, int group, int skip,
+                          const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream);
+
+/* GroupNorm(32 groups) per frame on NHWC fp16 [frames, hw, C] -> fp16 [frames*hw, C]
+ * (motion_module.py:84,110). `partial` is workspace of frames*chunks*groups*2 floats. */
+int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps,
+                           int frames, int hw, int C, int groups, float* partial, int chunks, vda_stream_t stream);
+
+/* ---------------------------------------------------------------- attention
+ * Spatial self-attention of the ViT (dinov2_layers/attention.py:51-59 or the xformers
+ * call at :76): qkv fp16 [B, N, 3, heads, 64] -> out fp16 [B, N, heads*64],
+ * softmax(q k^T / 8) v with fp32 softmax, never materialising the N x N scores. */
+int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream);
+/* Debug cross-check: 1 (default) = V^T fragments via ds_read_b64_tr_b16, 0 = scalar LDS reads. */
+int vda_attention_set_variant(int v);
+
+/* Temporal attention across T frames per pixel (motion_module.py:232-295,
+ * motion_module/attention.py:182-211): qkv fp16 [T*hw, 3*C] frame-major rows,
+ * 8 heads of d = C/8 -> out fp16 [T*hw, C]. Batch b>1 is expressed by calling per clip. */
+int vda_temporal_attention_f16(const void* qkv, void* out, int T, int hw, int C, int heads, vda_stream_t stream);
+
+/* ---------------------------------------------------------------- resampling / layout
+ * Bilinear, align_corners=True (util/blocks.py:156-158, dpt_temporal.py:94-96,
+ * video_depth.py:162,208). NHWC fp16 -> NHWC fp16, optional elementwise add of `add`
+ * (same shape as out). */
+int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add, int B, int h, int w, int H, int W, int C,
+                          vda_stream_t stream);
+/* fp32 planes [B,h,w] -> [B,H,W], optional relu (video_depth.py:162-163,208). */
+int vda_bilinear_plane_f32(const float* in, float* out, int B, int h, int w, int H, int W, int relu, vda_stream_t stream);
+
+/* Patch gather for the 14x14/s14 patch-embed conv (patch_embed.py:76): fp32 NCHW
+ * [B,3,H,W] -> fp16 [B*(H/14)*(W/14), Kpad], column = c*196 + ky*14 + kx, zero padded to Kpad. */
+int vda_patchify_f32_f16(const float* x, void* out, int B, int H, int W, int Kpad, vda_stream_t stream);
+
+/* cls rows of the token matrix: tok[b*(P+1), :] = cls + pos[0] (dinov2.py:218-219). */
+int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int P, int D, vda_stream_t stream);
+
+/* Final 1x1 conv 32->1 + ReLU on NHWC fp16 [rows, Cpad] (first 32 channels used)
+ * -> fp32 [rows] (dpt.py:121-122). */
+int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream);
+
+/* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
+ * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */
+int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,285 @@
+"""Per-kernel parity: every C-ABI entry point against a plain
+torch fp32 CPU evaluation of the same op on the same fp16-rounded operands.
+
+Tolerances: operands are fp16 (rel 2^-11 per element), accumulation fp32; outputs are compared
+with  max|y - ref| <= atol + rtol*|ref|  where rtol covers the final fp16 rounding of the output
+(2^-10) and atol the accumulated operand rounding over K terms."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F16, F32 = torch.float16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; run them with -m gpu on the MI355X box only")
+    from video_depth_anything_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(y, ref, rtol=2e-3, atol=2e-3, what=""):
+    y = y.detach().float().cpu()
+    ref = ref.float()
+    err = (y - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tolerance, max err {float(err.max()):.4g} (ref absmax {float(ref.abs().max()):.4g})"
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+# ---------------------------------------------------------------- GEMM epilogues
+@pytest.mark.parametrize("M,N,K", [(300, 192, 128), (128, 64, 64), (1000, 48, 192), (257, 384, 1536), (4100, 1024, 1024)])
+def test_gemm_bias(ops, M, N, K):
+    from video_depth_anything_amd import _lib
+    A = rnd(M, K, seed=1).to(F16)
+    W = rnd(N, K, seed=2, scale=K ** -0.5).to(F16)
+    b = rnd(N, seed=3)
+    out = torch.empty(M, N, dtype=F16, device="cuda")
+    ops.gemm(dev(A), dev(W), out, _lib.EPI_BIAS_F16, M=M, N=N, K=K, bias=dev(b))
+    ref = A.float() @ W.float().t() + b
+    close(out, ref, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_gelu_relu_f32(ops):
+    from video_depth_anything_amd import _lib
+    M, N, K = 515, 256, 320
+    A, W, b = rnd(M, K, seed=4).to(F16), rnd(N, K, seed=5, scale=K ** -0.5).to(F16), rnd(N, seed=6)
+    base = A.float() @ W.float().t() + b
+    for epi, fn, dt in ((_lib.EPI_BIAS_GELU_F16, F.gelu, F16), (_lib.EPI_BIAS_RELU_F16, F.relu, F16), (_lib.EPI_BIAS_F32, lambda x: x, F32)):
+        out = torch.empty(M, N, dtype=dt, device="cuda")
+        ops.gemm(dev(A), dev(W), out, epi, M=M, N=N, K=K, bias=dev(b))
+        close(out, fn(base), what=f"epilogue {epi}")
+
+
+def test_gemm_scale_residual_inplace(ops):
+    from video_depth_anything_amd import _lib
+    M, N, K = 777, 384, 384
+    A, W = rnd(M, K, seed=7).to(F16), rnd(N, K, seed=8, scale=K ** -0.5).to(F16)
+    b, gamma, res = rnd(N, seed=9), rnd(N, seed=10), rnd(M, N, seed=11, scale=3.0)
+    x = dev(res.clone())
+    ops.gemm(dev(A), dev(W), x, _lib.EPI_SCALE_RES_F32, M=M, N=N, K=K, bias=dev(b), gamma=dev(gamma), res=x)
+    ref = res + gamma * (A.float() @ W.float().t() + b)
+    close(x, ref, rtol=1e-5, atol=2e-3, what="scale+residual fp32")
+
+
+def test_gemm_res_f16_two_residuals(ops):
+    from video_depth_anything_amd import _lib
+    M, N, K = 300, 64, 128
+    A, W, b = rnd(M, K, seed=12).to(F16), rnd(N, K, seed=13, scale=K ** -0.5).to(F16), rnd(N, seed=14)
+    r1, r2 = rnd(M, N, seed=15).to(F16), rnd(M, N, seed=16).to(F16)
+    out = torch.empty(M, N, dtype=F16, device="cuda")
+    ops.gemm(dev(A), dev(W), out, _lib.EPI_RES_F16, M=M, N=N, K=K, bias=dev(b), res=dev(r1), res2=dev(r2))
+    close(out, A.float() @ W.float().t() + b + r1.float() + r2.float(), what="res f16 x2")
+
+
+def test_gemm_geglu(ops):
+    from video_depth_anything_amd import _lib
+    M, Cc = 333, 64
+    A = rnd(M, Cc, seed=17).to(F16)
+    w, b = rnd(8 * Cc, Cc, seed=18, scale=Cc ** -0.5), rnd(8 * Cc, seed=19)
+    wi, bi = ops.pack_geglu(w, b)
+    out = torch.empty(M, 4 * Cc, dtype=F16, device="cuda")
+    ops.gemm(dev(A), dev(wi), out, _lib.EPI_GEGLU_F16, M=M, N=8 * Cc, K=Cc, ldc=4 * Cc, bias=dev(bi))
+    p = A.float() @ w.to(F16).float().t() + b
+    val, gate = p.chunk(2, dim=-1)
+    close(out, val * F.gelu(gate), what="geglu")
+
+
+def test_gemm_patch_embed(ops):
+    from video_depth_anything_amd import _lib
+    B, H, W_, D = 3, 42, 56, 128
+    ph, pw = H // 14, W_ // 14
+    P = ph * pw
+    x = rnd(B, 3, H, W_, seed=20)
+    w, b = rnd(D, 3, 14, 14, seed=21, scale=588 ** -0.5), rnd(D, seed=22)
+    pos, cls = rnd(P + 1, D, seed=23), rnd(D, seed=24)
+    Kp = 640
+    a = torch.zeros(B * P, Kp, dtype=F16, device="cuda")
+    ops.patchify(dev(x), a, B, H, W_, Kp)
+    tok = torch.full((B, P + 1, D), float("nan"), dtype=F32, device="cuda")
+    wp = ops.pack_linear(w.reshape(D, 588), k_pad=Kp)
+    ops.gemm(a, dev(wp), tok, _lib.EPI_PATCH_F32, M=B * P, N=D, K=Kp, bias=dev(b), pos=dev(pos), P=P)
+    ops.cls_rows(tok, dev(cls), dev(pos), B, P, D)
+    ref = F.conv2d(x.to(F16).float(), w.to(F16).float(), b, stride=14).flatten(2).transpose(1, 2)
+    ref = torch.cat((cls.expand(B, 1, D), ref), dim=1) + pos
+    close(tok, ref, what="patch embed tokens")
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_gemm_convtranspose(ops, k):
+    from video_depth_anything_amd import _lib
+    B, h, w_, Cc = 2, 5, 7, 48
+    Cp = 64
+    x = rnd(B, Cc, h, w_, seed=25).to(F16)
+    wt, b = rnd(Cc, Cc, k, k, seed=26, scale=Cc ** -0.5), rnd(Cc, seed=27)
+    xin = torch.zeros(B, h, w_, Cp, dtype=F16)
+    xin[..., :Cc] = x.permute(0, 2, 3, 1)
+    wp, bp = ops.pack_convt(wt, b, Cp)
+    out = torch.empty(B, h * k, w_ * k, Cp, dtype=F16, device="cuda")
+    ops.gemm(dev(xin), dev(wp), out, _lib.EPI_CONVT_F16, M=B * h * w_, N=k * k * Cp, K=Cp, ldc=Cp, bias=dev(bp), convt=(k, h, w_, Cp))
+    ref = F.conv_transpose2d(x.float(), wt.to(F16).float(), b, stride=k).permute(0, 2, 3, 1)
+    close(out[..., :Cc], ref, what=f"convT k={k}")
+    assert float(out[..., Cc:].abs().max()) == 0.0, "pad channels must stay zero"
+
+
+@pytest.mark.parametrize("stride,relu_in,Cin,Cout,H,W_", [(1, False, 64, 64, 9, 11), (1, True, 128, 256, 12, 7), (2, False, 64, 128, 9, 9),
+                                                        (1, True, 64, 32, 20, 20)])
+def test_conv3x3(ops, stride, relu_in, Cin, Cout, H, W_):
+    from video_depth_anything_amd import _lib
+    B = 3
+    x = rnd(B, Cin, H, W_, seed=28).to(F16)
+    w, b = rnd(Cout, Cin, 3, 3, seed=29, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=30)
+    res = rnd(B, (H - 1) // stride + 1, (W_ - 1) // stride + 1, Cout, seed=31).to(F16)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W_ + 2 - 3) // stride + 1
+    xin = x.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(B, Ho, Wo, Cout, dtype=F16, device="cuda")
+    ops.gemm(dev(xin), dev(ops.pack_conv3x3(w)), out, _lib.EPI_RES_F16, M=B * Ho * Wo, N=Cout, K=9 * Cin, bias=dev(b), res=dev(res),
+             relu_in=relu_in, conv=(B, H, W_, Cin, Ho, Wo, stride))
+    xi = F.relu(x.float()) if relu_in else x.float()
+    ref = F.conv2d(xi, w.to(F16).float(), b, stride=stride, padding=1).permute(0, 2, 3, 1) + res.float()
+    close(out, ref, what="conv3x3")
+
+
+# ---------------------------------------------------------------- norms
+@pytest.mark.parametrize("D,rows", [(384, 50), (1024, 37), (128, 9), (64, 130)])
+def test_layernorm(ops, D, rows):
+    x, w, b = rnd(rows, D, seed=32, scale=3.0) + 0.5, rnd(D, seed=33) + 1.0, rnd(D, seed=34)
+    out = torch.empty(rows, D, dtype=F16, device="cuda")
+    ops.layernorm(dev(x), out, dev(w), dev(b), 1e-6, rows, D)
+    close(out, F.layer_norm(x, (D,), w, b, 1e-6), what="layernorm")
+
+
+def test_layernorm_drop_cls_and_pe(ops):
+    D, G, nb = 128, 13, 4
+    x, w, b = rnd(nb * G, D, seed=35), rnd(D, seed=36) + 1.0, rnd(D, seed=37)
+    out = torch.empty(nb * (G - 1), D, dtype=F16, device="cuda")
+    ops.layernorm(dev(x), out, dev(w), dev(b), 1e-6, nb * G, D, group=G, skip=1)
+    ref = F.layer_norm(x, (D,), w, b, 1e-6).reshape(nb, G, D)[:, 1:].reshape(-1, D)
+    close(out, ref, what="layernorm drop cls")
+    T, hw = 4, 6
+    x = rnd(T * hw, D, seed=38)
+    pe = rnd(T, D, seed=39)
+    out = torch.empty(T * hw, D, dtype=F16, device="cuda")
+    ops.layernorm(dev(x), out, dev(w), dev(b), 1e-5, T * hw, D, pe=dev(pe), pe_rows_per_step=hw, pe_steps=T)
+    ref = F.layer_norm(x, (D,), w, b, 1e-5).reshape(T, hw, D) + pe[:, None]
+    close(out, ref.reshape(-1, D), what="layernorm + pe")
+
+
+@pytest.mark.parametrize("Cc,hw,frames", [(64, 37, 3), (192, 50, 2), (1024, 19, 2), (384, 361, 2)])
+def test_groupnorm(ops, Cc, hw, frames):
+    x = (rnd(frames, hw, Cc, seed=40, scale=2.0) + 0.7).to(F16)
+    w, b = rnd(Cc, seed=41) + 1.0, rnd(Cc, seed=42)
+    chunks = min(8, hw)
+    part = torch.empty(frames * chunks * 32 * 2, dtype=F32, device="cuda")
+    out = torch.empty(frames, hw, Cc, dtype=F16, device="cuda")
+    ops.groupnorm(dev(x), out, dev(w), dev(b), 1e-6, frames, hw, Cc, 32, part, chunks)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, w, b, 1e-6).permute(0, 2, 1)
+    close(out, ref, rtol=3e-3, atol=3e-3, what="groupnorm")
+
+
+# ---------------------------------------------------------------- attention
+def attn_ref(qkv, B, N, H):
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    a = ((q * 0.125) @ k.transpose(-2, -1)).softmax(dim=-1)
+    return (a @ v).transpose(1, 2).reshape(B, N, H * 64)
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("B,N,H", [(2, 13, 2), (1, 64, 1), (2, 200, 3), (1, 1370, 2)])
+def test_attention(ops, B, N, H, variant):
+    from video_depth_anything_amd._lib import lib
+    qkv = rnd(B, N, 3 * H * 64, seed=43, scale=1.5).to(F16)
+    out = torch.full((B, N, H * 64), float("nan"), dtype=F16, device="cuda")
+    lib.vda_attention_set_variant(variant)
+    try:
+        ops.attention(dev(qkv), out, B, N, H)
+    finally:
+        lib.vda_attention_set_variant(1)
+    close(out, attn_ref(qkv, B, N, H), rtol=3e-3, atol=3e-3, what=f"attention variant {variant}")
+
+
+def test_attention_spiked_scores(ops):
+    """Online-softmax rescale path: one key dominates late in the sequence (guide rule 26)."""
+    B, N, H = 1, 300, 1
+    qkv = rnd(B, N, 3 * 64, seed=44).to(F16)
+    qkv[0, 250, 64:128] = qkv[0, 5, 0:64] * 6.0          # key 250 aligned with query 5
+    out = torch.empty(B, N, 64, dtype=F16, device="cuda")
+    ops.attention(dev(qkv), out, B, N, H)
+    close(out, attn_ref(qkv, B, N, H), rtol=3e-3, atol=3e-3, what="attention spiked")
+
+
+@pytest.mark.parametrize("Cc,T,hw", [(64, 32, 10), (64, 4, 12), (128, 7, 5), (192, 32, 6), (384, 32, 3), (256, 32, 4), (1024, 32, 3)])
+def test_temporal_attention(ops, Cc, T, hw):
+    heads, d = 8, Cc // 8
+    qkv = rnd(T * hw, 3 * Cc, seed=45).to(F16)
+    out = torch.full((T * hw, Cc), float("nan"), dtype=F16, device="cuda")
+    ops.temporal_attention(dev(qkv), out, T, hw, Cc)
+    x = qkv.float().reshape(T, hw, 3, heads, d).permute(2, 1, 3, 0, 4)      # [3, hw, heads, T, d]
+    a = (x[0] @ x[1].transpose(-1, -2) * d ** -0.5).softmax(dim=-1)
+    ref = (a @ x[2]).permute(2, 0, 1, 3).reshape(T * hw, Cc)
+    close(out, ref, what="temporal attention")
+
+
+# ---------------------------------------------------------------- resampling / layout
+@pytest.mark.parametrize("h,w_,H,W_", [(19, 19, 37, 37), (5, 7, 10, 14), (8, 6, 8, 6), (3, 4, 42, 56)])
+def test_bilinear_nhwc(ops, h, w_, H, W_):
+    B, Cc = 2, 64
+    x = rnd(B, Cc, h, w_, seed=46).to(F16)
+    add = rnd(B, H, W_, Cc, seed=47).to(F16)
+    out = torch.empty(B, H, W_, Cc, dtype=F16, device="cuda")
+    ops.bilinear_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), out, B, h, w_, H, W_, Cc, add=dev(add))
+    ref = F.interpolate(x.float(), size=(H, W_), mode="bilinear", align_corners=True).permute(0, 2, 3, 1) + add.float()
+    close(out, ref, what="bilinear nhwc")
+
+
+def test_bilinear_plane_and_identity(ops):
+    x = rnd(3, 20, 30, seed=48)
+    out = torch.empty(3, 45, 50, dtype=F32, device="cuda")
+    ops.bilinear_plane(dev(x), out, 3, 20, 30, 45, 50, relu=True)
+    ref = F.relu(F.interpolate(x[:, None], size=(45, 50), mode="bilinear", align_corners=True)[:, 0])
+    close(out, ref, rtol=1e-5, atol=1e-5, what="bilinear plane")
+    out = torch.empty(3, 20, 30, dtype=F32, device="cuda")
+    ops.bilinear_plane(dev(x), out, 3, 20, 30, 20, 30)
+    assert torch.equal(out.cpu(), x), "identity resize must be exact"
+
+
+def test_head_out_and_normalize(ops):
+    rows, Cp = 1000, 64
+    x = rnd(rows, Cp, seed=49).to(F16)
+    w = rnd(32, seed=50)
+    out = torch.empty(rows, dtype=F32, device="cuda")
+    ops.head_out(dev(x), dev(w), 0.3, out, rows, Cp)
+    close(out, F.relu(x[:, :32].float() @ w + 0.3), rtol=1e-4, atol=1e-4, what="head out")
+    rng = np.random.default_rng(5)
+    fr = rng.integers(0, 256, (3, 14, 28, 3), dtype=np.uint8)
+    o = torch.empty(3, 3, 14, 28, dtype=F32, device="cuda")
+    ops.normalize_u8(torch.from_numpy(fr).cuda(), o, 3, 14, 28)
+    ref = ((fr.astype(np.float32) / 255.0 - [0.485, 0.456, 0.406]) / [0.229, 0.224, 0.225]).astype(np.float32).transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(o.cpu().numpy(), ref)
+
+
+def test_refusals(ops):
+    """Bad geometry is refused with a message, nothing is launched."""
+    from video_depth_anything_amd import _lib
+    A, W = torch.zeros(8, 96, dtype=F16, device="cuda"), torch.zeros(8, 96, dtype=F16, device="cuda")
+    out = torch.zeros(8, 8, dtype=F16, device="cuda")
+    with pytest.raises(_lib.VdaError, match="multiple of 64"):
+        ops.gemm(A, W, out, _lib.EPI_BIAS_F16, M=8, N=8, K=96)
+    with pytest.raises(_lib.VdaError):
+        ops.temporal_attention(torch.zeros(40 * 3 * 64, dtype=F16, device="cuda"), torch.zeros(40 * 64, dtype=F16, device="cuda"), 40, 1, 64)

@@ -1,0 +1,69 @@
+"""ctypes binding of libvda_hip.so (include/vda.h). There is no CPU fallback:
+if the library is missing or does not export a symbol, importing this fails."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvda_hip.so")
+
+A_DENSE, A_CONV3X3 = 0, 1
+(EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RELU_F16, EPI_SCALE_RES_F32, EPI_RES_F16, EPI_GEGLU_F16,
+ EPI_PATCH_F32, EPI_CONVT_F16, EPI_BIAS_F32) = range(9)
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+        ("res", C.c_void_p), ("res2", C.c_void_p), ("gamma", C.c_void_p), ("pos", C.c_void_p),
+        ("zero_page", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("lda", C.c_int32), ("ldc", C.c_int32),
+        ("a_mode", C.c_int32), ("epilogue", C.c_int32), ("relu_in", C.c_int32),
+        ("cB", C.c_int32), ("cH", C.c_int32), ("cW", C.c_int32), ("cCin", C.c_int32),
+        ("cHo", C.c_int32), ("cWo", C.c_int32), ("cStride", C.c_int32),
+        ("P", C.c_int32), ("tK", C.c_int32), ("tH", C.c_int32), ("tW", C.c_int32), ("tCout", C.c_int32),
+    ]
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+SIGNATURES = {
+    "vda_last_error": (C.c_char_p, []),
+    "vda_abi_version": (_i, []),
+    "vda_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vda_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "vda_attention_set_variant": (_i, [_i]),
+    "vda_temporal_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_bilinear_nhwc_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vda_bilinear_plane_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vda_patchify_f32_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_cls_rows_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vda_head_out_f16_f32": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
+    "vda_normalize_u8_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+}
+
+
+class VdaError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m video_depth_anything_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise VdaError(f"{what}: {lib.vda_last_error().decode()} (rc={rc})")

@@ -1,0 +1,222 @@
+// Spatial self-attention of the ViT encoder for gfx950: softmax(q k^T / 8) v, head dim 64,
+// fp16 in / fp16 out, fp32 scores, softmax and accumulation; the N x N score matrix never
+// leaves registers (online softmax over 64-key tiles).
+//
+// Work split: one workgroup = 128 queries of one (frame, head); 4 waves x 32 queries.
+// Per 64-key tile and wave:
+//   S^T[key][query] = K_tile . Q^T    v_mfma_f32_32x32x16_f16, K rows from LDS (A operand),
+//                                     Q fragments held in registers for the whole kernel (B operand).
+//     -> a lane owns ONE query (lane & 31) and 32 of the tile's 64 keys in registers; its partner
+//        lane ^ 32 owns the other 32, so row max / row sum are in-lane plus one cross-lane exchange.
+//   O^T[ch][query] += V_tile^T . P^T  the exponentiated accumulators, converted to fp16 in place, ARE
+//                                     the B operand (k order permuted: element j of lane half h of
+//                                     16-key step s is key 16s + 8(j>>2) + 4h + (j&3)); V^T comes from
+//                                     the row-major V tile with ds_read_b64_tr_b16 in the same k order.
+//     -> the output accumulator also has the query on the lane, so the online-softmax rescale is a
+//        plain per-lane multiply.
+// K and V tiles arrive by 16-byte global_load_lds into a double buffer; XOR swizzles are applied on
+// the source address (the DMA image is lane-linear) and again on the LDS read.
+#include "vda_common.h"
+
+namespace {
+
+constexpr int HD = 64;       // head dim (both ViT-S and ViT-L)
+constexpr int BQ = 128;      // queries per workgroup
+constexpr int BKV = 64;      // keys per tile
+constexpr int TILE_BYTES = BKV * HD * 2;          // 8 KiB
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;       // K + V
+
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }          // 16-row conflict-free for 32-row b128 fragments
+__device__ __forceinline__ int v_swz(int row) { return ((row >> 1) & 1) << 2; }   // separates the 4 rows of a tr16 block
+
+template <bool TR>
+__global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
+                                                   int nqb, int total_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware remap: blocks sharing an XCD (bid % 8) get whole (frame, head) groups so K/V stay in that L2.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = total_blocks >> 3, rm = total_blocks & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int bh = t / nqb, qb = t - bh * nqb;
+    const int b = bh / H, head = bh - b * H;
+
+    const size_t rs = (size_t)3 * H * HD;                       // row stride of qkv in halves
+    const h16* Qb = qkv + (size_t)b * N * rs + head * HD;
+    const h16* Kb = Qb + (size_t)H * HD;
+    const h16* Vb = Kb + (size_t)H * HD;
+
+    // ---- Q fragments (B operand: lane holds Q[query r][16ks + 8h .. +7]), pre-scaled by 1/8 (exact)
+    const int q_row = qb * BQ + wave * 32 + r;
+    h16x8 qf[4];
+    {
+        const h16* qp = Qb + (size_t)min(q_row, N - 1) * rs + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const h16x8*>(qp + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = qf[ks][e] * (h16)0.125f;
+        }
+    }
+
+    // ---- DMA sources: each wave moves 2 K pieces and 2 V pieces (8 rows x 128 B each) per tile
+    const int lrow = lane >> 3, lpos = lane & 7;
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j;
+            const int row = piece * 8 + lrow;
+            const size_t key = (size_t)min(kt * BKV + row, N - 1);
+            glds16(Kb + key * rs + ((lpos ^ k_swz(row)) << 3), buf + piece * 1024);
+            glds16(Vb + key * rs + ((lpos ^ v_swz(row)) << 3), buf + TILE_BYTES + piece * 1024);
+        }
+    };
+
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    const int nt = (N + BKV - 1) / BKV;
+    stage(0, smem);
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        const char* Kt = smem + cur * STAGE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+
+        // ---- S^T = K . Q^T for the tile's two 32-key halves
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+            const int row = sub * 32 + r;
+            const char* kp = Kt + row * 128;
+            const int sw = k_swz(row);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+            }
+        }
+        // accumulator register e of half `sub` is key  kt*64 + sub*32 + (e&3) + 8*(e>>2) + 4h
+        if (kt == nt - 1 && (N % BKV) != 0) {
+            const int kbase = kt * BKV + 4 * h;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase + sub * 32 + (e & 3) + 8 * (e >> 2) >= N) s[sub][e] = -1e30f;
+        }
+
+        // ---- online softmax (per query = per lane pair {lane, lane^32})
+        float mx = s[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * LOG2E);
+        const float mb = m_new * LOG2E;
+        float psum = 0.f;
+        h16x8 pf[4];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = exp2f(s[sub][e] * LOG2E - mb);
+                psum += pv;
+                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+
+        // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
+#pragma unroll
+        for (int kstep = 0; kstep < 4; ++kstep) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h16x8 vf;
+                if constexpr (TR) {
+                    // 16-lane group reads a 4-key x 16-channel block; lane 4q+p addresses key q, channels 4p..4p+3.
+                    const int i = lane & 15, qq = i >> 2, pp = i & 3;
+                    const int col = c * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int key = kstep * 16 + half * 8 + 4 * h + qq;
+                        const char* ap = Vt + key * 128 + ((((col >> 3) ^ v_swz(key))) << 4) + ((col & 7) << 1);
+                        const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((VDA_LDS_AS fp16x4_t*)ap);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vf[half * 4 + e] = (h16)v4[e];
+                    }
+                } else {
+                    const int ch = c * 32 + r;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = kstep * 16 + 8 * (j >> 2) + 4 * h + (j & 3);
+                        vf[j] = *reinterpret_cast<const h16*>(Vt + key * 128 + ((((ch >> 3) ^ v_swz(key))) << 4) + ((ch & 7) << 1));
+                    }
+                }
+                acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
+            }
+        }
+        cur ^= 1;
+    }
+
+    // ---- normalise and store: lane holds query r, channels c*32 + (e&3) + 8*(e>>2) + 4h
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < N) {
+        h16* op = out + ((size_t)b * N + q_row) * ((size_t)H * HD) + head * HD + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o = {(h16)(acc_o[c][4 * g + 0] * inv), (h16)(acc_o[c][4 * g + 1] * inv),
+                           (h16)(acc_o[c][4 * g + 2] * inv), (h16)(acc_o[c][4 * g + 3] * inv)};
+                *reinterpret_cast<h16x4*>(op + c * 32 + 8 * g) = o;
+            }
+    }
+}
+
+}  // namespace
+
+static int g_attn_variant = 1;   // 1: ds_read_b64_tr_b16 V fragments, 0: scalar LDS reads (debug cross-check)
+
+extern "C" int vda_attention_set_variant(int v) {
+    g_attn_variant = v ? 1 : 0;
+    return 0;
+}
+
+extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream) {
+    VDA_REQUIRE(qkv && out, "vda_attention_f16: null pointer");
+    VDA_REQUIRE(B > 0 && N > 0 && heads > 0, "vda_attention_f16: empty problem B=%d N=%d heads=%d", B, N, heads);
+    VDA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "vda_attention_f16: 16-byte alignment required");
+    const int nqb = (N + BQ - 1) / BQ;
+    const long long total = (long long)nqb * B * heads;
+    VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (g_attn_variant)
+        hipLaunchKernelGGL((attn_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else
+        hipLaunchKernelGGL((attn_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}

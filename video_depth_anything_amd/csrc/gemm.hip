@@ -1,0 +1,311 @@
+// fp16 MFMA GEMM / implicit-GEMM conv for gfx950 (MI355X).
+//
+//   out = epilogue( A[M,K] * W[N,K]^T )          fp16 operands, fp32 accumulate
+//
+// Both operands are K-contiguous, which is exactly the v_mfma_f32_16x16x32_f16 fragment
+// shape (8 consecutive k per lane), so tiles go HBM -> LDS with 16-byte
+// global_load_lds (no VGPR round trip) and LDS -> VGPR with ds_read_b128.
+//
+// Tile: BM x BN x 64, 4 waves (2 x 2), each wave (BM/2) x (BN/2) as 16x16 MFMA subtiles.
+// LDS image per operand tile: [rows][8 chunks of 16 B] with chunk ^= (row & 7). The DMA
+// writes LDS linearly (wave-uniform base + lane*16), so the swizzle is applied to the
+// per-lane SOURCE address and again on the ds_read address (same involution both sides).
+// The MFMA is issued with W as the "A" operand and the activation tile as "B", so a lane's
+// 4 accumulator registers are 4 CONSECUTIVE output columns of one row: bias / LayerScale /
+// residual are read and the result stored as one 8- or 16-byte access per subtile.
+//
+// A-operand generators: dense rows, or the 3x3/pad-1 window of an NHWC tensor
+// (K ordered (ky,kx,ci); a 64-wide K step never straddles a tap because Cin % 64 == 0).
+// Rows past M / N are clamped on load and dropped on store.
+#include "vda_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 64;                 // halves per K step
+constexpr int ROW_BYTES = BK * 2;      // 128 B per tile row
+constexpr int NWAVES = 4;
+constexpr int NTHREADS = NWAVES * 64;
+
+template <int EPI>
+__device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, f32x4 v, f32x4 g) {
+    // v: accumulators for columns n..n+3 of row m (g: gate accumulators, GEGLU only).
+    if (m >= p.M || n >= p.N) return;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if constexpr (EPI == VDA_EPI_BIAS_F16 || EPI == VDA_EPI_BIAS_GELU_F16 || EPI == VDA_EPI_BIAS_RELU_F16) {
+        if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        }
+        if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
+        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
+        const size_t off = (size_t)m * p.ldc + n;
+        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
+        *reinterpret_cast<f32x4*>((float*)p.out + off) = v;
+    } else if constexpr (EPI == VDA_EPI_RES_F16) {
+        const size_t off = (size_t)m * p.ldc + n;
+        h16x4 r = *reinterpret_cast<const h16x4*>((const h16*)p.res + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
+        if (p.res2) {
+            h16x4 r2 = *reinterpret_cast<const h16x4*>((const h16*)p.res2 + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)r2[i];
+        }
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
+    } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+        // n indexes the interleaved weight rows [16 value | 16 gate] per 32; g belongs to n + 16.
+        if (p.bias) g += *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+        const int oc = (n >> 5) * 16 + (n & 15);
+        h16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (h16)(v[i] * gelu_erf(g[i]));
+        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + oc) = o;
+    } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
+        const int f = m / p.P, q = m - f * p.P;
+        v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + q) * p.N + n);
+        *reinterpret_cast<f32x4*>((float*)p.out + ((size_t)f * (p.P + 1) + 1 + q) * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
+        // m = (b, y, x) over the tH x tW input; n = (ky*k + kx)*Cout + co (bias pre-expanded to N).
+        const int k = p.tK, Co = p.tCout;
+        const int tap = n / Co, co = n - tap * Co;
+        const int ky = tap / k, kx = tap - ky * k;
+        const int hw = p.tH * p.tW;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.tW, x = rem - y * p.tW;
+        const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)x * k + kx;
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + orow * p.ldc + co) = o;
+    } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
+    }
+}
+
+template <int BM, int BN, int AMODE>
+__global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
+    constexpr int WTM = BM / 2, WTN = BN / 2;     // wave tile
+    constexpr int MI = WTM / 16, NI = WTN / 16;   // 16x16 subtiles per wave
+    constexpr int AJ = BM / 8 / NWAVES;           // 1-KiB DMA pieces per wave, A tile
+    constexpr int WJ = BN / 8 / NWAVES;
+    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + W_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- block -> tile, XCD-aware: blocks that share an XCD (bid % 8) get a contiguous run of
+    // tiles with the N index fastest, so an A row panel stays in that XCD's L2 across its N tiles.
+    const int nbn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int bm = t / nbn, bn = t - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // ---- per-lane DMA sources
+    const int lrow = lane >> 3;                   // row inside an 8-row piece
+    const int lchk = ((lane & 7) ^ lrow) * 8;     // swizzled source chunk, in halves
+    const h16* a_src[AJ];
+    int a_pix[AJ], a_iy0[AJ], a_ix0[AJ];
+    const h16* w_src[WJ];
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) {
+        int m = m0 + (wave + NWAVES * j) * 8 + lrow;
+        if constexpr (AMODE == VDA_A_DENSE) {
+            m = min(m, p.M - 1);
+            a_src[j] = (const h16*)p.A + (size_t)m * p.lda + lchk;
+        } else {
+            const bool ok = m < p.M;
+            m = min(m, p.M - 1);
+            const int hw = p.cHo * p.cWo;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.cWo, ox = rem - oy * p.cWo;
+            a_pix[j] = b * p.cH * p.cW;
+            a_iy0[j] = ok ? oy * p.cStride - 1 : -100000;
+            a_ix0[j] = ox * p.cStride - 1;
+            a_src[j] = (const h16*)p.A + lchk;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int n = min(n0 + (wave + NWAVES * j) * 8 + lrow, p.N - 1);
+        w_src[j] = (const h16*)p.W + (size_t)n * p.K + lchk;
+    }
+
+    auto stage = [&](int kt, char* buf) {
+        const int k0 = kt * BK;
+        if constexpr (AMODE == VDA_A_DENSE) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) glds16(a_src[j] + k0, buf + (wave + NWAVES * j) * 1024);
+        } else {
+            const int tap = k0 / p.cCin, ci0 = k0 - tap * p.cCin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int iy = a_iy0[j] + ky, ix = a_ix0[j] + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                const h16* src = ok ? a_src[j] + ((size_t)(a_pix[j] + iy * p.cW + ix) * p.cCin + ci0)
+                                    : (const h16*)p.zero_page + lchk;
+                glds16(src, buf + (wave + NWAVES * j) * 1024);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) glds16(w_src[j] + k0, buf + A_BYTES + (wave + NWAVES * j) * 1024);
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row = lane&15 (so row&7 == lane&7), k-chunk = ks*4 + (lane>>4)
+    const int frow = lane & 15, fchk = lane >> 4, fsw = lane & 7;
+    const bool relu_in = p.relu_in != 0;
+
+    auto compute = [&](const char* buf) {
+        const char* At = buf + (wm * WTM + frow) * ROW_BYTES;
+        const char* Wt = buf + A_BYTES + (wn * WTN + frow) * ROW_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = ((ks * 4 + fchk) ^ fsw) << 4;
+            h16x8 af[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(At + i * 16 * ROW_BYTES + coff);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const h16x8*>(Wt + j * 16 * ROW_BYTES + coff);
+            if (relu_in) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[i][e] = af[i][e] > (h16)0 ? af[i][e] : (h16)0;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nt = p.K / BK;
+    stage(0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE);
+        compute(smem + cur * STAGE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds, per subtile, 4 consecutive columns of one row
+    const int em = m0 + wm * WTM + (lane & 15);
+    const int en = n0 + wn * WTN + (lane >> 4) * 4;
+    auto run = [&](auto epi_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
+        if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; j += 2) store_one<EPI>(p, em + i * 16, en + j * 16, acc[i][j], acc[i][j + 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) store_one<EPI>(p, em + i * 16, en + j * 16, acc[i][j], acc[i][j]);
+        }
+    };
+    switch (p.epilogue) {
+        case VDA_EPI_BIAS_F16: run(std::integral_constant<int, VDA_EPI_BIAS_F16>{}); break;
+        case VDA_EPI_BIAS_GELU_F16: run(std::integral_constant<int, VDA_EPI_BIAS_GELU_F16>{}); break;
+        case VDA_EPI_BIAS_RELU_F16: run(std::integral_constant<int, VDA_EPI_BIAS_RELU_F16>{}); break;
+        case VDA_EPI_SCALE_RES_F32: run(std::integral_constant<int, VDA_EPI_SCALE_RES_F32>{}); break;
+        case VDA_EPI_RES_F16: run(std::integral_constant<int, VDA_EPI_RES_F16>{}); break;
+        case VDA_EPI_GEGLU_F16: run(std::integral_constant<int, VDA_EPI_GEGLU_F16>{}); break;
+        case VDA_EPI_PATCH_F32: run(std::integral_constant<int, VDA_EPI_PATCH_F32>{}); break;
+        case VDA_EPI_CONVT_F16: run(std::integral_constant<int, VDA_EPI_CONVT_F16>{}); break;
+        case VDA_EPI_BIAS_F32: run(std::integral_constant<int, VDA_EPI_BIAS_F32>{}); break;
+        default: break;
+    }
+}
+
+template <int BM, int BN, int AMODE>
+int launch(const vda_gemm_args& a, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AMODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AMODE>), dim3(nbm * nbn), dim3(NTHREADS), smem, s, a);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
+    VDA_REQUIRE(args != nullptr, "vda_gemm_f16: null args");
+    const vda_gemm_args& a = *args;
+    VDA_REQUIRE(a.A && a.W && a.out, "vda_gemm_f16: null operand");
+    VDA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "vda_gemm_f16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    VDA_REQUIRE(a.K % BK == 0, "vda_gemm_f16: K=%d must be a multiple of %d (pad at pack time)", a.K, BK);
+    VDA_REQUIRE(a.N % 4 == 0 && a.ldc % 4 == 0, "vda_gemm_f16: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
+    VDA_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.out & 15) == 0,
+                "vda_gemm_f16: operands must be 16-byte aligned");
+    VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_BIAS_F32, "vda_gemm_f16: bad epilogue %d", a.epilogue);
+    if (a.a_mode == VDA_A_DENSE) {
+        VDA_REQUIRE(a.lda >= a.K && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K and a multiple of 8", a.lda);
+    } else if (a.a_mode == VDA_A_CONV3X3) {
+        VDA_REQUIRE(a.zero_page != nullptr, "vda_gemm_f16: conv needs zero_page");
+        VDA_REQUIRE(a.cCin % BK == 0 && a.K == 9 * a.cCin, "vda_gemm_f16: conv needs Cin%%64==0 and K==9*Cin (Cin=%d K=%d)", a.cCin, a.K);
+        VDA_REQUIRE(a.cStride == 1 || a.cStride == 2, "vda_gemm_f16: conv stride %d", a.cStride);
+        VDA_REQUIRE(a.cHo == (a.cH + 2 - 3) / a.cStride + 1 && a.cWo == (a.cW + 2 - 3) / a.cStride + 1,
+                    "vda_gemm_f16: conv output size mismatch");
+        VDA_REQUIRE(a.M == a.cB * a.cHo * a.cWo, "vda_gemm_f16: conv M=%d != B*Ho*Wo", a.M);
+        VDA_REQUIRE((long long)a.cB * a.cH * a.cW * a.cCin < (1ll << 31), "vda_gemm_f16: conv input too large for 32-bit pixel index");
+    } else {
+        VDA_REQUIRE(false, "vda_gemm_f16: bad a_mode %d", a.a_mode);
+    }
+    switch (a.epilogue) {
+        case VDA_EPI_SCALE_RES_F32:
+        case VDA_EPI_RES_F16:
+            VDA_REQUIRE(a.res != nullptr, "vda_gemm_f16: residual epilogue needs res");
+            break;
+        case VDA_EPI_GEGLU_F16:
+            VDA_REQUIRE(a.N % 32 == 0, "vda_gemm_f16: GEGLU needs N%%32==0");
+            break;
+        case VDA_EPI_PATCH_F32:
+            VDA_REQUIRE(a.pos != nullptr && a.P > 0 && a.M % a.P == 0, "vda_gemm_f16: patch epilogue needs pos and M%%P==0");
+            break;
+        case VDA_EPI_CONVT_F16:
+            VDA_REQUIRE(a.tK > 0 && a.tCout > 0 && a.tCout % 4 == 0 && a.N == a.tK * a.tK * a.tCout && a.M % (a.tH * a.tW) == 0,
+                        "vda_gemm_f16: bad ConvTranspose geometry");
+            break;
+        default:
+            break;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool narrow = a.N <= 64;
+    if (a.a_mode == VDA_A_DENSE) return narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
+    return narrow ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
+}

@@ -1,0 +1,201 @@
+// LayerNorm (fp32 rows -> fp16) and per-frame GroupNorm (NHWC fp16 -> token-major fp16) for gfx950.
+// Both are HBM-bound streaming kernels: 16-byte accesses, statistics in fp32, one pass over the
+// data for LayerNorm (row kept in registers), two launches with a fixed-order (deterministic)
+// partial-sum tree for GroupNorm.
+#include "vda_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm
+// One wave per row; a lane keeps up to MAXV float4 of the row in registers (D <= 64*4*MAXV).
+constexpr int LN_MAXV = 8;
+
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ in, h16* __restrict__ out,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, int rows, int D, int group, int skip,
+                                                        const float* __restrict__ pe, int pe_rows_per_step, int pe_steps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int orow = row;
+    if (group > 0) {
+        const int g = row / group, i = row - g * group;
+        if (i < skip) return;                                   // dropped row (cls token)
+        orow = g * (group - skip) + (i - skip);
+    }
+    const int nv = D >> 2;                                      // float4 per row
+    const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)row * D);
+    f32x4 v[LN_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nv) {
+            v[j] = src[idx];
+            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[j][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    const float* per = nullptr;
+    if (pe) per = pe + (size_t)((row / pe_rows_per_step) % pe_steps) * D;
+    h16* dst = out + (size_t)orow * D;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int idx = lane + 64 * j;
+        if (idx < nv) {
+            const f32x4 ww = reinterpret_cast<const f32x4*>(w)[idx];
+            const f32x4 bb = reinterpret_cast<const f32x4*>(b)[idx];
+            f32x4 y = (v[j] - mean) * rstd * ww + bb;
+            if (per) y += reinterpret_cast<const f32x4*>(per)[idx];
+            h16x4 o = {(h16)y[0], (h16)y[1], (h16)y[2], (h16)y[3]};
+            reinterpret_cast<h16x4*>(dst)[idx] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- GroupNorm
+// Stage 1: grid (chunks, frames). A block sums x and x^2 per channel over its rows of one frame,
+// folds channels into groups in a fixed order, writes partial[frame][chunk][group][2].
+__global__ void __launch_bounds__(256) groupnorm_partial_kernel(const h16* __restrict__ in, float* __restrict__ partial,
+                                                                int hw, int C, int groups, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rows_par][C][2] then [C][2]
+    const int frame = blockIdx.y, chunk = blockIdx.x;
+    const int nv = C >> 3;                       // 16-byte vectors per row
+    const int rows_par = 256 / nv;               // rows processed concurrently (>= 2 for C <= 1024)
+    const int tid = threadIdx.x;
+    const int rl = tid / nv, vi = tid - rl * nv;
+    const int rows_per_chunk = (hw + chunks - 1) / chunks;
+    const int r0 = chunk * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (rl < rows_par) {
+        const h16* base = in + (size_t)frame * hw * C + vi * 8;
+        for (int r = r0 + rl; r < r1; r += rows_par) {
+            const h16x8 x = *reinterpret_cast<const h16x8*>(base + (size_t)r * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)x[e];
+                s[e] += f;
+                q[e] += f * f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[((size_t)rl * C + vi * 8 + e) * 2 + 0] = s[e];
+            red[((size_t)rl * C + vi * 8 + e) * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    float* chs = red + (size_t)rows_par * C * 2;                 // per-channel totals
+    for (int c = tid; c < C; c += 256) {
+        float a = 0.f, bq = 0.f;
+        for (int k = 0; k < rows_par; ++k) {
+            a += red[((size_t)k * C + c) * 2 + 0];
+            bq += red[((size_t)k * C + c) * 2 + 1];
+        }
+        chs[c * 2 + 0] = a;
+        chs[c * 2 + 1] = bq;
+    }
+    __syncthreads();
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float a = 0.f, bq = 0.f;
+        for (int k = 0; k < cpg; ++k) {
+            a += chs[(tid * cpg + k) * 2 + 0];
+            bq += chs[(tid * cpg + k) * 2 + 1];
+        }
+        float* p = partial + (((size_t)frame * chunks + chunk) * groups + tid) * 2;
+        p[0] = a;
+        p[1] = bq;
+    }
+}
+
+// Stage 2: grid (row blocks, frames). Combine the frame's partials (double, fixed order), normalise.
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const h16* __restrict__ in, h16* __restrict__ out,
+                                                              const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ partial, float eps, int hw, int C,
+                                                              int groups, int chunks, int rows_per_block) {
+    __shared__ float mean_s[64], rstd_s[64];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / groups;
+    if (tid < groups) {
+        double a = 0.0, q = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            const float* p = partial + (((size_t)frame * chunks + k) * groups + tid) * 2;
+            a += (double)p[0];
+            q += (double)p[1];
+        }
+        const double n = (double)hw * cpg;
+        const double mean = a / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int nv = C >> 3;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(hw, r0 + rows_per_block);
+    const size_t fbase = (size_t)frame * hw * C;
+    for (int idx = tid; idx < (r1 - r0) * nv; idx += 256) {
+        const int r = r0 + idx / nv, vi = idx % nv;
+        const size_t off = fbase + (size_t)r * C + vi * 8;
+        const h16x8 x = *reinterpret_cast<const h16x8*>(in + off);
+        h16x8 y;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = vi * 8 + e;
+            const int g = c / cpg;
+            y[e] = (h16)(((float)x[e] - mean_s[g]) * rstd_s[g] * w[c] + b[c]);
+        }
+        *reinterpret_cast<h16x8*>(out + off) = y;
+    }
+}
+
+}  // namespace
+
+extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const float* b, float eps, int rows, int D,
+                                     int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
+                                     vda_stream_t stream) {
+    VDA_REQUIRE(in && out && w && b, "vda_layernorm: null pointer");
+    VDA_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "vda_layernorm: D=%d must be a multiple of 4 and <= %d", D,
+                64 * 4 * LN_MAXV);
+    VDA_REQUIRE(group == 0 || (group > 0 && skip >= 0 && skip < group && rows % group == 0), "vda_layernorm: bad group/skip");
+    VDA_REQUIRE(pe == nullptr || (pe_rows_per_step > 0 && pe_steps > 0), "vda_layernorm: bad pe geometry");
+    VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0, "vda_layernorm: alignment");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, in, (h16*)out, w, b, eps, rows, D,
+                       group, skip, pe, pe_rows_per_step, pe_steps);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps, int frames, int hw,
+                                      int C, int groups, float* partial, int chunks, vda_stream_t stream) {
+    VDA_REQUIRE(in && out && w && b && partial, "vda_groupnorm: null pointer");
+    VDA_REQUIRE(frames > 0 && hw > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C % 8 == 0 && C <= 1024,
+                "vda_groupnorm: bad geometry C=%d groups=%d", C, groups);
+    VDA_REQUIRE(chunks > 0 && chunks <= hw, "vda_groupnorm: chunks=%d out of range", chunks);
+    const int nv = C / 8, rows_par = 256 / nv;
+    const size_t smem = ((size_t)rows_par * C * 2 + (size_t)C * 2) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(chunks, frames), dim3(256), smem, s, (const h16*)in, partial, hw, C, groups, chunks);
+    VDA_LAUNCH_CHECK();
+    const int rows_per_block = 32;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((hw + rows_per_block - 1) / rows_per_block, frames), dim3(256), 0, s,
+                       (const h16*)in, (h16*)out, w, b, partial, eps, hw, C, groups, chunks, rows_per_block);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,188 @@
+// Streaming (HBM-bound) layout and resampling kernels for gfx950: bilinear align_corners=True
+// resizes, patch gather for the patch-embed GEMM, cls rows, the 32->1 output projection and the
+// uint8 -> normalised fp32 frame conversion. All use 16-byte per-lane accesses where the layout
+// allows; grids are capped and grid-strided.
+#include "vda_common.h"
+
+namespace {
+
+__device__ __forceinline__ void lerp_coord(int dst, int in, int outn, int& i0, int& i1, float& w1) {
+    // align_corners=True source coordinate: dst * (in-1)/(out-1)
+    const float scale = outn > 1 ? (float)(in - 1) / (float)(outn - 1) : 0.f;
+    const float src = scale * (float)dst;
+    i0 = min((int)src, in - 1);
+    i1 = min(i0 + 1, in - 1);
+    w1 = src - (float)i0;
+}
+
+__global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const h16* __restrict__ in, h16* __restrict__ out,
+                                                            const h16* __restrict__ add, int B, int h, int w, int H, int W, int C) {
+    const int nv = C >> 3;
+    const size_t total = (size_t)B * H * W * nv;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int v = (int)(idx % nv);
+        size_t pix = idx / nv;
+        const int X = (int)(pix % W);
+        pix /= W;
+        const int Y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        lerp_coord(Y, h, H, y0, y1, wy);
+        lerp_coord(X, w, W, x0, x1, wx);
+        const h16* base = in + (size_t)b * h * w * C + v * 8;
+        const h16x8 a00 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * w + x0) * C);
+        const h16x8 a01 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * w + x1) * C);
+        const h16x8 a10 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * w + x0) * C);
+        const h16x8 a11 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * w + x1) * C);
+        h16x8 o;
+        h16x8 ad = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (add) ad = *reinterpret_cast<const h16x8*>(add + idx * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float top = (float)a00[e] * (1.f - wx) + (float)a01[e] * wx;
+            const float bot = (float)a10[e] * (1.f - wx) + (float)a11[e] * wx;
+            o[e] = (h16)(top * (1.f - wy) + bot * wy + (float)ad[e]);
+        }
+        *reinterpret_cast<h16x8*>(out + idx * 8) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) bilinear_plane_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int h,
+                                                             int w, int H, int W, int relu) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int X = (int)(idx % W);
+        const size_t t = idx / W;
+        const int Y = (int)(t % H);
+        const int b = (int)(t / H);
+        int y0, y1, x0, x1;
+        float wy, wx;
+        lerp_coord(Y, h, H, y0, y1, wy);
+        lerp_coord(X, w, W, x0, x1, wx);
+        const float* base = in + (size_t)b * h * w;
+        const float top = base[(size_t)y0 * w + x0] * (1.f - wx) + base[(size_t)y0 * w + x1] * wx;
+        const float bot = base[(size_t)y1 * w + x0] * (1.f - wx) + base[(size_t)y1 * w + x1] * wx;
+        float o = top * (1.f - wy) + bot * wy;
+        if (relu) o = fmaxf(o, 0.f);
+        out[idx] = o;
+    }
+}
+
+// Block = one patch row of one frame: reads 3*14 image rows (coalesced), scatters them into the
+// pw patch rows of the GEMM A matrix (column = c*196 + ky*14 + kx).
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ x, h16* __restrict__ out, int H, int W, int Kpad) {
+    const int pw = W / 14, ph = H / 14;
+    const int py = blockIdx.x, b = blockIdx.y;
+    const int n = 3 * 14 * W;
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int c = idx / (14 * W), rem = idx - c * 14 * W;
+        const int ky = rem / W, xx = rem - ky * W;
+        const int px = xx / 14, kx = xx - px * 14;
+        if (px >= pw) continue;
+        const float v = x[(((size_t)b * 3 + c) * H + py * 14 + ky) * W + xx];
+        out[((size_t)(b * ph + py) * pw + px) * Kpad + c * 196 + ky * 14 + kx] = (h16)v;
+    }
+}
+
+__global__ void cls_rows_kernel(float* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos, int B, int P,
+                                int D) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, c = idx - b * D;
+    tok[(size_t)b * (P + 1) * D + c] = cls[c] + pos[c];
+}
+
+__global__ void __launch_bounds__(256) head_out_kernel(const h16* __restrict__ in, const float* __restrict__ w, float bias,
+                                                       float* __restrict__ out, int rows, int Cpad) {
+    // 4 lanes per row, 8 channels each (32 live channels), reduced with two shuffles.
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = gid >> 2;
+    const int part = (int)(gid & 3);
+    float a = 0.f;
+    if (row < (size_t)rows) {
+        const h16x8 x = *reinterpret_cast<const h16x8*>(in + row * Cpad + part * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += (float)x[e] * w[part * 8 + e];
+    }
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (row < (size_t)rows && part == 0) out[row] = fmaxf(a + bias, 0.f);
+}
+
+__global__ void __launch_bounds__(256) normalize_u8_kernel(const uint8_t* __restrict__ f, float* __restrict__ out, int n, int H, int W) {
+    const size_t hw = (size_t)H * W, total = (size_t)n * hw;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t fr = idx / hw, pix = idx - fr * hw;
+        const uint8_t* p = f + idx * 3;
+        // reference arithmetic: float32(x)/255 (fp32), then (v - mean)/std in float64, cast to fp32
+        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)p[c] / 255.0f;
+            out[(fr * 3 + c) * hw + pix] = (float)(((double)v - mean[c]) / stdv[c]);
+        }
+    }
+}
+
+inline unsigned capped_grid(size_t work_items) {
+    size_t blocks = (work_items + 255) / 256;
+    const size_t cap = 256 * 16;
+    return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add, int B, int h, int w, int H, int W, int C,
+                                     vda_stream_t stream) {
+    VDA_REQUIRE(in && out, "vda_bilinear_nhwc: null pointer");
+    VDA_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "vda_bilinear_nhwc: bad geometry");
+    VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)add & 15) == 0, "vda_bilinear_nhwc: alignment");
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out,
+                       (const h16*)add, B, h, w, H, W, C);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_bilinear_plane_f32(const float* in, float* out, int B, int h, int w, int H, int W, int relu, vda_stream_t stream) {
+    VDA_REQUIRE(in && out, "vda_bilinear_plane: null pointer");
+    VDA_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "vda_bilinear_plane: bad geometry");
+    hipLaunchKernelGGL(bilinear_plane_kernel, dim3(capped_grid((size_t)B * H * W)), dim3(256), 0, (hipStream_t)stream, in, out, B, h, w,
+                       H, W, relu);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_patchify_f32_f16(const float* x, void* out, int B, int H, int W, int Kpad, vda_stream_t stream) {
+    VDA_REQUIRE(x && out, "vda_patchify: null pointer");
+    VDA_REQUIRE(B > 0 && H > 0 && W > 0 && H % 14 == 0 && W % 14 == 0, "vda_patchify: H=%d W=%d must be multiples of 14", H, W);
+    VDA_REQUIRE(Kpad >= 588, "vda_patchify: Kpad=%d < 588", Kpad);
+    hipLaunchKernelGGL(patchify_kernel, dim3(H / 14, B), dim3(256), 0, (hipStream_t)stream, x, (h16*)out, H, W, Kpad);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int P, int D, vda_stream_t stream) {
+    VDA_REQUIRE(tok && cls && pos && B > 0 && P > 0 && D > 0, "vda_cls_rows: bad arguments");
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, tok, cls, pos, B, P, D);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream) {
+    VDA_REQUIRE(in && w && out && rows > 0, "vda_head_out: bad arguments");
+    VDA_REQUIRE(Cpad >= 32 && Cpad % 8 == 0 && ((uintptr_t)in & 15) == 0, "vda_head_out: Cpad=%d must be >=32, multiple of 8", Cpad);
+    const size_t threads = (size_t)rows * 4;
+    hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, w,
+                       bias, out, rows, Cpad);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream) {
+    VDA_REQUIRE(frames && out && n > 0 && H > 0 && W > 0, "vda_normalize_u8: bad arguments");
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3(capped_grid((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames, out, n, H, W);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}

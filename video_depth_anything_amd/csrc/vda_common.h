@@ -1,0 +1,55 @@
+// Shared device helpers for the gfx950 kernels. Wave = 64 lanes throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vda.h"
+
+typedef _Float16 h16;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VDA_GLOBAL_AS __attribute__((address_space(1)))
+#define VDA_LDS_AS __attribute__((address_space(3)))
+
+extern "C" void vda_set_error(const char* fmt, ...);
+
+#define VDA_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            vda_set_error(__VA_ARGS__);        \
+            return 1;                          \
+        }                                      \
+    } while (0)
+
+#define VDA_LAUNCH_CHECK()                                             \
+    do {                                                               \
+        hipError_t e_ = hipGetLastError();                             \
+        if (e_ != hipSuccess) {                                        \
+            vda_set_error("launch failed: %s", hipGetErrorString(e_)); \
+            return 2;                                                  \
+        }                                                              \
+    } while (0)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 16-byte async global -> LDS copy. The LDS destination is the wave-uniform `lds_base`
+// plus lane*16 (hardware rule); the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds((const VDA_GLOBAL_AS void*)gsrc, (VDA_LDS_AS void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

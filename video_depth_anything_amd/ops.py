@@ -1,0 +1,173 @@
+"""Thin tensor -> pointer wrappers over the C ABI (include/vda.h).
+
+torch is used for device memory and the current HIP stream only; every op here
+is one call into libvda_hip.so and nothing else. Shapes are validated twice:
+here (tensor metadata the C side cannot see) and in the library (geometry).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check, lib
+
+F16, F32 = torch.float16, torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f"{name}: expected contiguous cuda {dtype}, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+_zero_pages = {}
+
+
+def zero_page(device):
+    z = _zero_pages.get(device)
+    if z is None:
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        _zero_pages[device] = z
+    return z
+
+
+def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, res2=None, gamma=None, pos=None,
+         relu_in=False, conv=None, P=0, convt=None):
+    """out = epilogue(A[M,K] W[N,K]^T). conv = (B,H,W,Cin,Ho,Wo,stride) switches A to the
+    implicit 3x3 window of an NHWC tensor; convt = (k, h, w, Cout) for VDA_EPI_CONVT_F16."""
+    _req(A, F16, "A"), _req(W, F16, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
+    a = GemmArgs()
+    a.A, a.W, a.bias, a.out = _p(A), _p(W), _p(bias), _p(out)
+    a.res, a.res2, a.gamma, a.pos = _p(res), _p(res2), _p(gamma), _p(pos)
+    a.zero_page = _p(zero_page(A.device))
+    a.M, a.N, a.K = M, N, K
+    a.lda = K if lda is None else lda
+    a.ldc = N if ldc is None else ldc
+    a.a_mode = _lib.A_DENSE if conv is None else _lib.A_CONV3X3
+    a.epilogue = epi
+    a.relu_in = 1 if relu_in else 0
+    if conv is not None:
+        a.cB, a.cH, a.cW, a.cCin, a.cHo, a.cWo, a.cStride = conv
+    a.P = P
+    if convt is not None:
+        a.tK, a.tH, a.tW, a.tCout = convt
+    if W.numel() < N * K:
+        raise ValueError("W smaller than N*K")
+    check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
+
+
+def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
+    _req(x, F32, "x"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(pe, F32, "pe")
+    check(lib.vda_layernorm_f32_f16(_p(x), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _p(pe), pe_rows_per_step,
+                                    pe_steps, _stream()), "vda_layernorm_f32_f16")
+
+
+def groupnorm(x, out, w, b, eps, frames, hw, Cc, groups, partial, chunks):
+    _req(x, F16, "x"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(partial, F32, "partial")
+    if partial.numel() < frames * chunks * groups * 2:
+        raise ValueError("groupnorm workspace too small")
+    check(lib.vda_groupnorm_nhwc_f16(_p(x), _p(out), _p(w), _p(b), eps, frames, hw, Cc, groups, _p(partial), chunks,
+                                     _stream()), "vda_groupnorm_nhwc_f16")
+
+
+def attention(qkv, out, B, N, heads):
+    _req(qkv, F16, "qkv"), _req(out, F16, "out")
+    if qkv.numel() < B * N * 3 * heads * 64 or out.numel() < B * N * heads * 64:
+        raise ValueError("attention buffers too small")
+    check(lib.vda_attention_f16(_p(qkv), _p(out), B, N, heads, _stream()), "vda_attention_f16")
+
+
+def temporal_attention(qkv, out, T, hw, Cc, heads=8):
+    _req(qkv, F16, "qkv"), _req(out, F16, "out")
+    if qkv.numel() < T * hw * 3 * Cc or out.numel() < T * hw * Cc:
+        raise ValueError("temporal attention buffers too small")
+    check(lib.vda_temporal_attention_f16(_p(qkv), _p(out), T, hw, Cc, heads, _stream()), "vda_temporal_attention_f16")
+
+
+def bilinear_nhwc(x, out, B, h, w, H, W, Cc, add=None):
+    _req(x, F16, "x"), _req(out, F16, "out"), _req(add, F16, "add")
+    check(lib.vda_bilinear_nhwc_f16(_p(x), _p(out), _p(add), B, h, w, H, W, Cc, _stream()), "vda_bilinear_nhwc_f16")
+
+
+def bilinear_plane(x, out, B, h, w, H, W, relu=False):
+    _req(x, F32, "x"), _req(out, F32, "out")
+    check(lib.vda_bilinear_plane_f32(_p(x), _p(out), B, h, w, H, W, 1 if relu else 0, _stream()), "vda_bilinear_plane_f32")
+
+
+def patchify(x, out, B, H, W, Kpad):
+    _req(x, F32, "x"), _req(out, F16, "out")
+    check(lib.vda_patchify_f32_f16(_p(x), _p(out), B, H, W, Kpad, _stream()), "vda_patchify_f32_f16")
+
+
+def cls_rows(tok, cls, pos, B, P, D):
+    _req(tok, F32, "tok"), _req(cls, F32, "cls"), _req(pos, F32, "pos")
+    check(lib.vda_cls_rows_f32(_p(tok), _p(cls), _p(pos), B, P, D, _stream()), "vda_cls_rows_f32")
+
+
+def head_out(x, w, bias, out, rows, Cpad):
+    _req(x, F16, "x"), _req(w, F32, "w"), _req(out, F32, "out")
+    check(lib.vda_head_out_f16_f32(_p(x), _p(w), float(bias), _p(out), rows, Cpad, _stream()), "vda_head_out_f16_f32")
+
+
+def normalize_u8(frames, out, n, H, W):
+    _req(frames, torch.uint8, "frames"), _req(out, F32, "out")
+    check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream()), "vda_normalize_u8_f32")
+
+
+# ---------------------------------------------------------------------------
+# Weight layouts the kernels expect (done once at load time, on the host or device)
+# ---------------------------------------------------------------------------
+def pad_to(n, m=64):
+    return (n + m - 1) // m * m
+
+
+def pack_linear(w, n_pad=None, k_pad=None):
+    """[N,K] fp32 -> fp16 [Npad,Kpad], zero padded."""
+    N, K = w.shape
+    n_pad = N if n_pad is None else n_pad
+    k_pad = K if k_pad is None else k_pad
+    o = torch.zeros(n_pad, k_pad, dtype=F16, device=w.device)
+    o[:N, :K] = w.to(F16)
+    return o
+
+
+def pack_conv3x3(w, cout_pad=None, cin_pad=None):
+    """Conv2d weight [Cout,Cin,3,3] -> fp16 [Coutpad, 9*Cinpad] with K ordered (ky,kx,ci)."""
+    Co, Ci = w.shape[:2]
+    cout_pad = Co if cout_pad is None else cout_pad
+    cin_pad = Ci if cin_pad is None else cin_pad
+    o = torch.zeros(cout_pad, 3, 3, cin_pad, dtype=F16, device=w.device)
+    o[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1).to(F16)
+    return o.reshape(cout_pad, 9 * cin_pad).contiguous()
+
+
+def pack_convt(w, bias, cpad):
+    """ConvTranspose2d (k == stride) weight [Cin,Cout,k,k] -> fp16 [(ky,kx,co) = k*k*cpad, cpad(ci)],
+    bias expanded to the same row order."""
+    Ci, Co, k, _ = w.shape
+    o = torch.zeros(k, k, cpad, cpad, dtype=F16, device=w.device)
+    o[:, :, :Co, :Ci] = w.permute(2, 3, 1, 0).to(F16)
+    bb = torch.zeros(k, k, cpad, dtype=F32, device=w.device)
+    bb[:, :, :Co] = bias.to(F32)
+    return o.reshape(k * k * cpad, cpad).contiguous(), bb.reshape(-1).contiguous()
+
+
+def pack_geglu(w, bias):
+    """GEGLU proj [8C, C]: rows [value(4C) | gate(4C)] -> interleaved [16 value | 16 gate] per 32 rows."""
+    two_n, K = w.shape
+    n = two_n // 2
+    assert n % 16 == 0
+    wv, wg = w[:n].reshape(n // 16, 16, K), w[n:].reshape(n // 16, 16, K)
+    wi = torch.stack((wv, wg), dim=1).reshape(two_n, K)
+    bv, bg = bias[:n].reshape(n // 16, 16), bias[n:].reshape(n // 16, 16)
+    bi = torch.stack((bv, bg), dim=1).reshape(two_n)
+    return wi.to(F16).contiguous(), bi.to(F32).contiguous()
