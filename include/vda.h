@@ -51,7 +51,8 @@ enum vda_epilogue {
     VDA_EPI_GEGLU_F16 = 5,       /* W rows interleaved [16 value | 16 gate]: out_h[m, n/2] = (acc_v+b_v) * gelu(acc_g+b_g)  attention.py:383-384 */
     VDA_EPI_PATCH_F32 = 6,       /* out_f[(m/P)*(P+1) + 1 + m%P, n] = acc + bias[n] + pos[(1 + m%P)*N + n]   dinov2.py:218-219 */
     VDA_EPI_CONVT_F16 = 7,       /* W rows ordered (ky,kx,co): pixel-shuffle scatter of a k==stride ConvTranspose2d  dpt.py:71-82 */
-    VDA_EPI_BIAS_F32 = 8         /* out_f[m,n] = acc + bias[n] */
+    VDA_EPI_BIAS_F32 = 8,        /* out_f[m,n] = acc + bias[n] */
+    VDA_EPI_SCALE_RES_F32_H = 9  /* out_h[m,n] = (fp16)(res_f[m,n] + gamma[n]*(acc + bias[n])): leaves an fp32 residual stream */
 };
 
 typedef struct vda_gemm_args {

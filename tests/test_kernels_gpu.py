@@ -78,6 +78,16 @@ def test_gemm_scale_residual_inplace(ops):
     close(x, ref, rtol=1e-5, atol=2e-3, what="scale+residual fp32")
 
 
+def test_gemm_scale_residual_f16_out(ops):
+    from video_depth_anything_amd import _lib
+    M, N, K = 260, 64, 256
+    A, W, b = rnd(M, K, seed=51).to(F16), rnd(N, K, seed=52, scale=K ** -0.5).to(F16), rnd(N, seed=53)
+    res = rnd(M, N, seed=54, scale=2.0)
+    out = torch.empty(M, N, dtype=F16, device="cuda")
+    ops.gemm(dev(A), dev(W), out, _lib.EPI_SCALE_RES_F32_H, M=M, N=N, K=K, bias=dev(b), res=dev(res))
+    close(out, res + A.float() @ W.float().t() + b, what="fp32 residual -> fp16 out")
+
+
 def test_gemm_res_f16_two_residuals(ops):
     from video_depth_anything_amd import _lib
     M, N, K = 300, 64, 128

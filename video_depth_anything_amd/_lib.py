@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libvda_hip.so")
 
 A_DENSE, A_CONV3X3 = 0, 1
 (EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RELU_F16, EPI_SCALE_RES_F32, EPI_RES_F16, EPI_GEGLU_F16,
- EPI_PATCH_F32, EPI_CONVT_F16, EPI_BIAS_F32) = range(9)
+ EPI_PATCH_F32, EPI_CONVT_F16, EPI_BIAS_F32, EPI_SCALE_RES_F32_H) = range(10)
 
 
 class GemmArgs(C.Structure):

@@ -85,6 +85,12 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
         *reinterpret_cast<h16x4*>((h16*)p.out + orow * p.ldc + co) = o;
     } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
         *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
+        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
+        const size_t off = (size_t)m * p.ldc + n;
+        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
     }
 }
 
@@ -238,6 +244,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
         case VDA_EPI_PATCH_F32: run(std::integral_constant<int, VDA_EPI_PATCH_F32>{}); break;
         case VDA_EPI_CONVT_F16: run(std::integral_constant<int, VDA_EPI_CONVT_F16>{}); break;
         case VDA_EPI_BIAS_F32: run(std::integral_constant<int, VDA_EPI_BIAS_F32>{}); break;
+        case VDA_EPI_SCALE_RES_F32_H: run(std::integral_constant<int, VDA_EPI_SCALE_RES_F32_H>{}); break;
         default: break;
     }
 }
@@ -272,7 +279,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     VDA_REQUIRE(a.N % 4 == 0 && a.ldc % 4 == 0, "vda_gemm_f16: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
     VDA_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.out & 15) == 0,
                 "vda_gemm_f16: operands must be 16-byte aligned");
-    VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_BIAS_F32, "vda_gemm_f16: bad epilogue %d", a.epilogue);
+    VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_SCALE_RES_F32_H, "vda_gemm_f16: bad epilogue %d", a.epilogue);
     if (a.a_mode == VDA_A_DENSE) {
         VDA_REQUIRE(a.lda >= a.K && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K and a multiple of 8", a.lda);
     } else if (a.a_mode == VDA_A_CONV3X3) {
@@ -288,6 +295,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     }
     switch (a.epilogue) {
         case VDA_EPI_SCALE_RES_F32:
+        case VDA_EPI_SCALE_RES_F32_H:
         case VDA_EPI_RES_F16:
             VDA_REQUIRE(a.res != nullptr, "vda_gemm_f16: residual epilogue needs res");
             break;

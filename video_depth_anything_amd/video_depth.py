@@ -1,0 +1,122 @@
+"""`VideoDepthAnything`: the drop-in class for the reference's model wrapper.
+
+Same constructor arguments, `load_state_dict(sd, strict=True)`, `forward(x)` and
+`infer_video_depth(frames, target_fps, input_size=518, device='cuda', fp32=False)` as
+/root/reference/video_depth_anything/video_depth.py:37-63,89-93,161-254, so the four callers
+(run.py:45-50, metric_depth/run.py:43-48, app.py:34-48, benchmark/infer/infer.py:36-58) can switch
+by changing one import. All arithmetic runs in libvda_hip.so; see engine.py.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from .config import INFER_LEN, get_config
+from .scheduler import network_size, run_windows
+
+_FP32_WARNED = False
+
+
+class VideoDepthAnything:
+    METRIC = False   # metric variant stitches with scale=1, shift=0 (metric_depth/.../video_depth.py:132)
+
+    def __init__(self, encoder='vits', features=64, out_channels=[48, 96, 192, 384], use_bn=False, use_clstoken=False,
+                 num_frames=32, pe='ape', **_unused):
+        # num_block / out_channel / conv of the fork's constructor (video_depth.py:47-49) are accepted and unused, as there.
+        if use_bn or use_clstoken or pe != 'ape':
+            raise NotImplementedError("only the released configuration (use_bn=False, use_clstoken=False, pe='ape') is built")
+        self.encoder = encoder
+        self.intermediate_layer_idx = {'vits': [2, 5, 8, 11], 'vitl': [4, 11, 17, 23]}
+        self.cfg = get_config(encoder, features, out_channels, num_frames)
+        self.engine = None
+        self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self._sd = None
+
+    # ---- nn.Module-like surface used by the callers -------------------------------------------
+    def load_state_dict(self, state_dict, strict=True):
+        from .weights import check_state_dict
+        check_state_dict(self.cfg, state_dict, strict)
+        self._sd = state_dict
+        if self.engine is not None:
+            self.engine.load_state_dict(state_dict, strict)
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError("video_depth_anything_amd runs on an MI355X HIP device only (got device=%r)" % (device,))
+        self._device = device
+        self._ensure_engine()
+        return self
+
+    def cuda(self):
+        return self.to('cuda')
+
+    def eval(self):
+        return self
+
+    def _ensure_engine(self):
+        if self.engine is None:
+            from .engine import Engine            # imports the HIP library; fails loudly if it is missing
+            self.engine = Engine(self.cfg, self._device)
+            if self._sd is not None:
+                self.engine.load_state_dict(self._sd, True)
+        return self.engine
+
+    # ---- forward -----------------------------------------------------------------------------
+    def forward(self, x):
+        """x [B,T,3,H,W] (H, W multiples of 14, T <= 32) -> depth fp32 [B,T,H,W]."""
+        return self._ensure_engine().forward(x)
+
+    __call__ = forward
+
+    # ---- video inference ---------------------------------------------------------------------
+    def _preprocess(self, frames_u8, H, W):
+        """uint8 [32,H0,W0,3] -> normalised fp32 [1,32,3,H,W] on the device."""
+        from . import ops
+        eng = self._ensure_engine()
+        n, H0, W0 = frames_u8.shape[:3]
+        dev_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(eng.device, non_blocking=True)
+        x = torch.empty(1, n, 3, H0, W0, dtype=torch.float32, device=eng.device)
+        ops.normalize_u8(dev_u8, x, n, H0, W0)
+        if (H0, W0) != (H, W):
+            # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is not
+            # available offline, so this leg is PARITY UNPINNED: bicubic (a=-0.75, half-pixel centres) on
+            # the device; normalisation is affine so resizing after it is equivalent.
+            x = torch.nn.functional.interpolate(x[0], size=(H, W), mode='bicubic', align_corners=False)[None]
+        return x
+
+    def infer_video_depth(self, frames, target_fps, input_size=518, device='cuda', fp32=False):
+        global _FP32_WARNED
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError("video_depth_anything_amd runs on an MI355X HIP device only (got device=%r)" % (device,))
+        if fp32 and not _FP32_WARNED:
+            warnings.warn("fp32=True: this build computes with fp16 MFMA operands and fp32 accumulation/residuals; "
+                          "an fp32-operand path is not built yet")
+            _FP32_WARNED = True
+        from . import ops
+        eng = self._ensure_engine()
+        frames = np.asarray(frames)
+        if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
+            frames = np.ascontiguousarray(frames).astype(np.uint8)
+        H0, W0 = frames.shape[1:3]
+        H, W = network_size(H0, W0, input_size)
+
+        def window_fn(win_u8):
+            x = self._preprocess(win_u8, H, W)
+            depth = eng.forward(x)                                           # [1,32,H,W] fp32
+            out = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=eng.device)
+            ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)   # video_depth.py:207-208
+            return out.cpu().numpy()                                         # one D2H per window
+
+        depths = run_windows(frames, window_fn, metric=self.METRIC)
+        return depths, target_fps
+
+
+class MetricVideoDepthAnything(VideoDepthAnything):
+    """metric_depth/video_depth_anything/video_depth.py: ViT-L defaults, no scale/shift alignment."""
+    METRIC = True
+
+    def __init__(self, encoder='vitl', features=256, out_channels=[256, 512, 1024, 1024], use_bn=False, use_clstoken=False,
+                 num_frames=32, pe='ape'):
+        super().__init__(encoder, features, out_channels, use_bn, use_clstoken, num_frames, pe)
