@@ -29,6 +29,10 @@ def _req(t, dtype, name):
         raise ValueError(f"{name}: expected contiguous cuda {dtype}, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
+# Optional per-launch timing (bench.py): when PROFILE is a list, every GEMM launch is bracketed by two
+# events recorded on the launch stream and appended as (kernel_name, algorithmic_flops, start, stop).
+PROFILE = None
+
 _zero_pages = {}
 
 
@@ -62,7 +66,15 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
         a.tK, a.tH, a.tW, a.tCout = convt
     if W.numel() < N * K:
         raise ValueError("W smaller than N*K")
+    if PROFILE is None:
+        check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
+    e1.record()
+    name = "gemm_kernel<128,%d,%s>" % (64 if N <= 64 else 128, "dense" if conv is None else "conv3x3")
+    PROFILE.append((name, 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
