@@ -49,11 +49,21 @@ class VdaError(RuntimeError):
 
 
 def _load():
+    # ONE HIP runtime per process: torch ships its own libamdhip64.so (soname libamdhip64.so.7, the one
+    # libvda_hip.so asks for). Load torch's first so ours binds to it; loading ours first would pull in
+    # /opt/rocm's copy as a second runtime whose streams and device state torch does not share.
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m video_depth_anything_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
     lib = C.CDLL(LIB_PATH)
+    runtimes = {l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l}
+    if len(runtimes) > 1:
+        raise ImportError(f"two HIP runtimes in one process: {sorted(runtimes)}")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
