@@ -76,6 +76,10 @@ typedef struct vda_gemm_args {
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
+/* Tuning hook: -1 (default) picks the tile per shape; 0 = 128-row tiles, 1 = 256x256, 2 = 256x128. */
+int vda_gemm_set_variant(int v);
+/* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
+const char* vda_gemm_last_kernel(void);
 
 /* ---------------------------------------------------------------- norms
  * LayerNorm over the last dim, fp32 statistics (dinov2.py:95,310; block.py:56,68;

@@ -24,6 +24,15 @@ def ops():
     return o
 
 
+@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "tile128", "tile256x256", "tile256x128"])
+def gemm_variant(request, ops):
+    """Run every GEMM/conv test under each tile family (the dispatcher normally picks per shape)."""
+    from video_depth_anything_amd._lib import lib
+    lib.vda_gemm_set_variant(request.param)
+    yield request.param
+    lib.vda_gemm_set_variant(-1)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -45,7 +54,7 @@ def dev(t, dtype=None):
 
 # ---------------------------------------------------------------- GEMM epilogues
 @pytest.mark.parametrize("M,N,K", [(300, 192, 128), (128, 64, 64), (1000, 48, 192), (257, 384, 1536), (4100, 1024, 1024)])
-def test_gemm_bias(ops, M, N, K):
+def test_gemm_bias(ops, gemm_variant, M, N, K):
     from video_depth_anything_amd import _lib
     A = rnd(M, K, seed=1).to(F16)
     W = rnd(N, K, seed=2, scale=K ** -0.5).to(F16)
@@ -56,7 +65,7 @@ def test_gemm_bias(ops, M, N, K):
     close(out, ref, what=f"gemm {M}x{N}x{K}")
 
 
-def test_gemm_gelu_relu_f32(ops):
+def test_gemm_gelu_relu_f32(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     M, N, K = 515, 256, 320
     A, W, b = rnd(M, K, seed=4).to(F16), rnd(N, K, seed=5, scale=K ** -0.5).to(F16), rnd(N, seed=6)
@@ -67,7 +76,7 @@ def test_gemm_gelu_relu_f32(ops):
         close(out, fn(base), what=f"epilogue {epi}")
 
 
-def test_gemm_scale_residual_inplace(ops):
+def test_gemm_scale_residual_inplace(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     M, N, K = 777, 384, 384
     A, W = rnd(M, K, seed=7).to(F16), rnd(N, K, seed=8, scale=K ** -0.5).to(F16)
@@ -78,7 +87,7 @@ def test_gemm_scale_residual_inplace(ops):
     close(x, ref, rtol=1e-5, atol=2e-3, what="scale+residual fp32")
 
 
-def test_gemm_scale_residual_f16_out(ops):
+def test_gemm_scale_residual_f16_out(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     M, N, K = 260, 64, 256
     A, W, b = rnd(M, K, seed=51).to(F16), rnd(N, K, seed=52, scale=K ** -0.5).to(F16), rnd(N, seed=53)
@@ -88,7 +97,7 @@ def test_gemm_scale_residual_f16_out(ops):
     close(out, res + A.float() @ W.float().t() + b, what="fp32 residual -> fp16 out")
 
 
-def test_gemm_res_f16_two_residuals(ops):
+def test_gemm_res_f16_two_residuals(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     M, N, K = 300, 64, 128
     A, W, b = rnd(M, K, seed=12).to(F16), rnd(N, K, seed=13, scale=K ** -0.5).to(F16), rnd(N, seed=14)
@@ -98,7 +107,7 @@ def test_gemm_res_f16_two_residuals(ops):
     close(out, A.float() @ W.float().t() + b + r1.float() + r2.float(), what="res f16 x2")
 
 
-def test_gemm_geglu(ops):
+def test_gemm_geglu(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     M, Cc = 333, 64
     A = rnd(M, Cc, seed=17).to(F16)
@@ -111,7 +120,23 @@ def test_gemm_geglu(ops):
     close(out, val * F.gelu(gate), what="geglu")
 
 
-def test_gemm_patch_embed(ops):
+def test_gemm_geglu_full_width_regression(ops):
+    """Temporal module 1 of ViT-L (M=11552, N=8192, K=1024): the large-tile epilogue once preloaded gate-lane
+    bias past the end of the tensor (a page fault when the bias ends a memory segment)."""
+    from video_depth_anything_amd import _lib
+    M, Cc = 11552, 1024
+    A = rnd(M, Cc, seed=60).to(F16)
+    w, b = rnd(8 * Cc, Cc, seed=61, scale=Cc ** -0.5), rnd(8 * Cc, seed=62)
+    wi, bi = ops.pack_geglu(w, b)
+    out = torch.empty(M, 4 * Cc, dtype=F16, device="cuda")
+    ops.gemm(dev(A), dev(wi), out, _lib.EPI_GEGLU_F16, M=M, N=8 * Cc, K=Cc, ldc=4 * Cc, bias=dev(bi))
+    sel = torch.arange(0, M, 97)
+    p = A[sel].float() @ w.to(F16).float().t() + b
+    val, gate = p.chunk(2, dim=-1)
+    close(out[sel.cuda()], val * F.gelu(gate), what="geglu full width")
+
+
+def test_gemm_patch_embed(ops, gemm_variant):
     from video_depth_anything_amd import _lib
     B, H, W_, D = 3, 42, 56, 128
     ph, pw = H // 14, W_ // 14
@@ -132,7 +157,7 @@ def test_gemm_patch_embed(ops):
 
 
 @pytest.mark.parametrize("k", [2, 4])
-def test_gemm_convtranspose(ops, k):
+def test_gemm_convtranspose(ops, gemm_variant, k):
     from video_depth_anything_amd import _lib
     B, h, w_, Cc = 2, 5, 7, 48
     Cp = 64
@@ -150,7 +175,7 @@ def test_gemm_convtranspose(ops, k):
 
 @pytest.mark.parametrize("stride,relu_in,Cin,Cout,H,W_", [(1, False, 64, 64, 9, 11), (1, True, 128, 256, 12, 7), (2, False, 64, 128, 9, 9),
                                                         (1, True, 64, 32, 20, 20)])
-def test_conv3x3(ops, stride, relu_in, Cin, Cout, H, W_):
+def test_conv3x3(ops, gemm_variant, stride, relu_in, Cin, Cout, H, W_):
     from video_depth_anything_amd import _lib
     B = 3
     x = rnd(B, Cin, H, W_, seed=28).to(F16)

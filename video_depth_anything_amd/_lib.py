@@ -30,6 +30,8 @@ SIGNATURES = {
     "vda_last_error": (C.c_char_p, []),
     "vda_abi_version": (_i, []),
     "vda_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "vda_gemm_set_variant": (_i, [_i]),
+    "vda_gemm_last_kernel": (C.c_char_p, []),
     "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -40,7 +40,7 @@ def _compile(src):
 
 def build(verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(_compile, _sources()))
     if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -17,82 +17,15 @@
 // A-operand generators: dense rows, or the 3x3/pad-1 window of an NHWC tensor
 // (K ordered (ky,kx,ci); a 64-wide K step never straddles a tap because Cin % 64 == 0).
 // Rows past M / N are clamped on load and dropped on store.
-#include "vda_common.h"
-#include <type_traits>
+#include "gemm_epilogue.h"
 
 namespace {
+using vda_gemm::store_one;
 
 constexpr int BK = 64;                 // halves per K step
 constexpr int ROW_BYTES = BK * 2;      // 128 B per tile row
 constexpr int NWAVES = 4;
 constexpr int NTHREADS = NWAVES * 64;
-
-template <int EPI>
-__device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, f32x4 v, f32x4 g) {
-    // v: accumulators for columns n..n+3 of row m (g: gate accumulators, GEGLU only).
-    if (m >= p.M || n >= p.N) return;
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    if constexpr (EPI == VDA_EPI_BIAS_F16 || EPI == VDA_EPI_BIAS_GELU_F16 || EPI == VDA_EPI_BIAS_RELU_F16) {
-        if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
-        }
-        if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + n) = o;
-    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
-        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
-        const size_t off = (size_t)m * p.ldc + n;
-        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
-        *reinterpret_cast<f32x4*>((float*)p.out + off) = v;
-    } else if constexpr (EPI == VDA_EPI_RES_F16) {
-        const size_t off = (size_t)m * p.ldc + n;
-        h16x4 r = *reinterpret_cast<const h16x4*>((const h16*)p.res + off);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
-        if (p.res2) {
-            h16x4 r2 = *reinterpret_cast<const h16x4*>((const h16*)p.res2 + off);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] += (float)r2[i];
-        }
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
-    } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
-        // n indexes the interleaved weight rows [16 value | 16 gate] per 32; g belongs to n + 16.
-        if (p.bias) g += *reinterpret_cast<const f32x4*>(p.bias + n + 16);
-        const int oc = (n >> 5) * 16 + (n & 15);
-        h16x4 o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (h16)(v[i] * gelu_erf(g[i]));
-        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + oc) = o;
-    } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
-        const int f = m / p.P, q = m - f * p.P;
-        v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + q) * p.N + n);
-        *reinterpret_cast<f32x4*>((float*)p.out + ((size_t)f * (p.P + 1) + 1 + q) * p.ldc + n) = v;
-    } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
-        // m = (b, y, x) over the tH x tW input; n = (ky*k + kx)*Cout + co (bias pre-expanded to N).
-        const int k = p.tK, Co = p.tCout;
-        const int tap = n / Co, co = n - tap * Co;
-        const int ky = tap / k, kx = tap - ky * k;
-        const int hw = p.tH * p.tW;
-        const int b = m / hw, rem = m - b * hw;
-        const int y = rem / p.tW, x = rem - y * p.tW;
-        const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)x * k + kx;
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-        *reinterpret_cast<h16x4*>((h16*)p.out + orow * p.ldc + co) = o;
-    } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
-        *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
-    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
-        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
-        const size_t off = (size_t)m * p.ldc + n;
-        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
-        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
-    }
-}
 
 template <int BM, int BN, int AMODE>
 __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
@@ -177,7 +110,10 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
 
     // fragment read offsets: row = lane&15 (so row&7 == lane&7), k-chunk = ks*4 + (lane>>4)
     const int frow = lane & 15, fchk = lane >> 4, fsw = lane & 7;
-    const bool relu_in = p.relu_in != 0;
+    const h16 relu_floor = p.relu_in ? (h16)0.f : (h16)(-65504.f);
+    h16x8 relu_thr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) relu_thr[e] = relu_floor;
 
     auto compute = [&](const char* buf) {
         const char* At = buf + (wm * WTM + frow) * ROW_BYTES;
@@ -190,11 +126,9 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const h16x8*>(At + i * 16 * ROW_BYTES + coff);
 #pragma unroll
             for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const h16x8*>(Wt + j * 16 * ROW_BYTES + coff);
-            if (relu_in) {
+            if constexpr (AMODE == VDA_A_CONV3X3) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) af[i][e] = af[i][e] > (h16)0 ? af[i][e] : (h16)0;
+                for (int i = 0; i < MI; ++i) af[i] = __builtin_elementwise_max(af[i], relu_thr);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -234,19 +168,7 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
                 for (int j = 0; j < NI; ++j) store_one<EPI>(p, em + i * 16, en + j * 16, acc[i][j], acc[i][j]);
         }
     };
-    switch (p.epilogue) {
-        case VDA_EPI_BIAS_F16: run(std::integral_constant<int, VDA_EPI_BIAS_F16>{}); break;
-        case VDA_EPI_BIAS_GELU_F16: run(std::integral_constant<int, VDA_EPI_BIAS_GELU_F16>{}); break;
-        case VDA_EPI_BIAS_RELU_F16: run(std::integral_constant<int, VDA_EPI_BIAS_RELU_F16>{}); break;
-        case VDA_EPI_SCALE_RES_F32: run(std::integral_constant<int, VDA_EPI_SCALE_RES_F32>{}); break;
-        case VDA_EPI_RES_F16: run(std::integral_constant<int, VDA_EPI_RES_F16>{}); break;
-        case VDA_EPI_GEGLU_F16: run(std::integral_constant<int, VDA_EPI_GEGLU_F16>{}); break;
-        case VDA_EPI_PATCH_F32: run(std::integral_constant<int, VDA_EPI_PATCH_F32>{}); break;
-        case VDA_EPI_CONVT_F16: run(std::integral_constant<int, VDA_EPI_CONVT_F16>{}); break;
-        case VDA_EPI_BIAS_F32: run(std::integral_constant<int, VDA_EPI_BIAS_F32>{}); break;
-        case VDA_EPI_SCALE_RES_F32_H: run(std::integral_constant<int, VDA_EPI_SCALE_RES_F32_H>{}); break;
-        default: break;
-    }
+    vda_gemm::dispatch_epilogue(p.epilogue, run);
 }
 
 template <int BM, int BN, int AMODE>
@@ -270,6 +192,28 @@ int launch(const vda_gemm_args& a, hipStream_t s) {
 
 }  // namespace
 
+// gemm256_*.hip: return -1 when the (A mode, epilogue) pair is not instantiated for the large tile
+int vda_gemm256_dense_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256_dense_bn128(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256_conv_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256_conv_bn128(const vda_gemm_args& a, hipStream_t s);
+
+static int vda_gemm256_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
+    if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256_dense_bn256(a, s) : vda_gemm256_dense_bn128(a, s);
+    return bn == 256 ? vda_gemm256_conv_bn256(a, s) : vda_gemm256_conv_bn128(a, s);
+}
+
+static int g_gemm_variant = -1;   // -1 auto, 0 = 128-row tiles only, 1 = 256x256, 2 = 256x128 (tuning / A-B runs)
+
+static thread_local const char* g_last_kernel = "";
+
+extern "C" const char* vda_gemm_last_kernel(void) { return g_last_kernel; }
+
+extern "C" int vda_gemm_set_variant(int v) {
+    g_gemm_variant = v;
+    return 0;
+}
+
 extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     VDA_REQUIRE(args != nullptr, "vda_gemm_f16: null args");
     const vda_gemm_args& a = *args;
@@ -281,7 +225,8 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
                 "vda_gemm_f16: operands must be 16-byte aligned");
     VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_SCALE_RES_F32_H, "vda_gemm_f16: bad epilogue %d", a.epilogue);
     if (a.a_mode == VDA_A_DENSE) {
-        VDA_REQUIRE(a.lda >= a.K && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K and a multiple of 8", a.lda);
+        VDA_REQUIRE((a.relu_in & 1) == 0, "vda_gemm_f16: relu_in is only built for the conv A operand");
+        VDA_REQUIRE((a.lda >= a.K || a.lda == 0) && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K (or 0 = broadcast row) and a multiple of 8", a.lda);
     } else if (a.a_mode == VDA_A_CONV3X3) {
         VDA_REQUIRE(a.zero_page != nullptr, "vda_gemm_f16: conv needs zero_page");
         VDA_REQUIRE(a.cCin % BK == 0 && a.K == 9 * a.cCin, "vda_gemm_f16: conv needs Cin%%64==0 and K==9*Cin (Cin=%d K=%d)", a.cCin, a.K);
@@ -313,6 +258,35 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             break;
     }
     hipStream_t s = (hipStream_t)stream;
+    const bool fits32 = (a.a_mode == VDA_A_DENSE ? (long long)a.M * a.lda : 0ll) + a.K < (1ll << 31) && (long long)a.N * a.K < (1ll << 31);
+    VDA_REQUIRE(fits32 || g_gemm_variant == 0 || g_gemm_variant < 0, "vda_gemm_f16: operand too large for the 256-row kernel's 32-bit offsets");
+    if (!fits32) {
+        const bool narrow0 = a.N <= 64;
+        if (a.a_mode == VDA_A_DENSE) return narrow0 ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
+        return narrow0 ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
+    }
+    int big = 0;
+    if (g_gemm_variant == 1) big = 256;
+    if (g_gemm_variant == 2) big = 128;
+    if (g_gemm_variant < 0 && a.N >= 192 && a.M >= 2048) {
+        // large-tile kernel; BN picked for the smaller padded width
+        const int pad256 = (a.N + 255) / 256 * 256, pad128 = (a.N + 127) / 128 * 128;
+        big = pad128 < pad256 ? 128 : 256;
+    }
+    if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
+        VDA_REQUIRE(g_gemm_variant < 0, "vda_gemm_f16: the 256-row kernel needs N and ldc to be multiples of 8");
+        big = 0;                            // its epilogue owns 8-column (16-byte) row segments
+    }
+    if (big) {
+        const int rc = vda_gemm256_launch(a, big, s);
+        if (rc >= 0) {
+            g_last_kernel = a.a_mode == VDA_A_DENSE ? (big == 256 ? "gemm256_kernel<256,dense>" : "gemm256_kernel<128,dense>")
+                                                    : (big == 256 ? "gemm256_kernel<256,conv3x3>" : "gemm256_kernel<128,conv3x3>");
+            return rc;
+        }                                   // -1: pair not built for the large tile, use the 128-row kernel
+    }
+    g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128,64,dense>" : "gemm_kernel<128,128,dense>")
+                                            : (a.N <= 64 ? "gemm_kernel<128,64,conv3x3>" : "gemm_kernel<128,128,conv3x3>");
     const bool narrow = a.N <= 64;
     if (a.a_mode == VDA_A_DENSE) return narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
     return narrow ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);

@@ -1,0 +1,263 @@
+// Epilogues shared by the GEMM kernels: the caller hands one row m and 4 consecutive output columns n..n+3
+// (fp32 accumulators); bias / activation / LayerScale / residual / layout scatter happen here.
+#pragma once
+#include "vda_common.h"
+#include <type_traits>
+
+namespace vda_gemm {
+
+template <int EPI>
+__device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, f32x4 v, f32x4 g) {
+    // v: accumulators for columns n..n+3 of row m (g: gate accumulators, GEGLU only).
+    if (m >= p.M || n >= p.N) return;
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if constexpr (EPI == VDA_EPI_BIAS_F16 || EPI == VDA_EPI_BIAS_GELU_F16 || EPI == VDA_EPI_BIAS_RELU_F16) {
+        if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_erf(v[i]);
+        }
+        if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + n) = o;
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
+        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
+        const size_t off = (size_t)m * p.ldc + n;
+        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
+        *reinterpret_cast<f32x4*>((float*)p.out + off) = v;
+    } else if constexpr (EPI == VDA_EPI_RES_F16) {
+        const size_t off = (size_t)m * p.ldc + n;
+        h16x4 r = *reinterpret_cast<const h16x4*>((const h16*)p.res + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
+        if (p.res2) {
+            h16x4 r2 = *reinterpret_cast<const h16x4*>((const h16*)p.res2 + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)r2[i];
+        }
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
+    } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+        // n indexes the interleaved weight rows [16 value | 16 gate] per 32; g belongs to n + 16.
+        if (p.bias) g += *reinterpret_cast<const f32x4*>(p.bias + n + 16);
+        const int oc = (n >> 5) * 16 + (n & 15);
+        h16x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (h16)(v[i] * gelu_erf(g[i]));
+        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + oc) = o;
+    } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
+        const int f = m / p.P, q = m - f * p.P;
+        v += *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + q) * p.N + n);
+        *reinterpret_cast<f32x4*>((float*)p.out + ((size_t)f * (p.P + 1) + 1 + q) * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
+        // m = (b, y, x) over the tH x tW input; n = (ky*k + kx)*Cout + co (bias pre-expanded to N).
+        const int k = p.tK, Co = p.tCout;
+        const int tap = n / Co, co = n - tap * Co;
+        const int ky = tap / k, kx = tap - ky * k;
+        const int hw = p.tH * p.tW;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.tW, x = rem - y * p.tW;
+        const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)x * k + kx;
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + orow * p.ldc + co) = o;
+    } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
+        if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
+        const size_t off = (size_t)m * p.ldc + n;
+        v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
+        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Row-layout epilogues (used after the accumulators have been transposed through LDS): the caller
+// hands NC consecutive columns n..n+NC-1 of ONE row m, so bias / LayerScale / residual reads and the
+// output store are contiguous 16-byte (or 32-byte) accesses and a wave instruction covers full lines.
+// fp16-output epilogues take NC = 8, fp32-output ones NC = 4. `g` = gate columns (GEGLU only).
+template <int EPI>
+struct RowTraits {
+    static constexpr bool f32_out = (EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_BIAS_F32 || EPI == VDA_EPI_PATCH_F32);
+    static constexpr int NC = f32_out ? 4 : 8;
+};
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i] = a[i];
+        v[4 + i] = b[i];
+    }
+}
+
+__device__ __forceinline__ void store8h(h16* p, const float (&v)[8]) {
+    h16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (h16)v[i];
+    *reinterpret_cast<h16x8*>(p) = o;
+}
+
+// Per-lane column constants (bias / LayerScale for the lane's NC columns), loaded once per tile.
+template <int NC>
+struct ColConst {
+    float bias[NC];
+    float gamma[NC];
+    float gbias[NC];     // GEGLU: bias of the gate columns n+16..
+};
+
+template <int EPI, int NC>
+__device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, ColConst<NC>& c) {
+    const bool ok = n < p.N;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        c.bias[i] = 0.f;
+        c.gamma[i] = 1.f;
+        c.gbias[i] = 0.f;
+    }
+    if (!ok) return;
+    if (p.bias) {
+#pragma unroll
+        for (int i = 0; i < NC; i += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c.bias[i + e] = t[e];
+        }
+        if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+            if ((n & 31) < 16) {        // value lanes only: for a gate lane n+16.. runs past the end of bias
+#pragma unroll
+            for (int i = 0; i < NC; i += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n + 16 + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c.gbias[i + e] = t[e];
+            }
+            }
+        }
+    }
+    if constexpr (EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H) {
+        if (p.gamma) {
+#pragma unroll
+            for (int i = 0; i < NC; i += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(p.gamma + n + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c.gamma[i + e] = t[e];
+            }
+        }
+    }
+}
+
+// Row-dependent operands fetched from memory (residuals, pos-embed). Loaded for a whole 32-row block BEFORE any
+// of the block's stores is issued: vmcnt retires in order and counts stores, so interleaving load/store pairs
+// would serialise one memory round trip per row group.
+struct RowAux {
+    f32x4 f0, f1;
+    h16x8 h0, h1;
+};
+
+template <int EPI>
+__device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int n, RowAux& x) {
+    if (m >= p.M || n >= p.N) return;
+    if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
+        x.f0 = *reinterpret_cast<const f32x4*>((const float*)p.res + (size_t)m * p.ldc + n);
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
+        const float* r = (const float*)p.res + (size_t)m * p.ldc + n;
+        x.f0 = *reinterpret_cast<const f32x4*>(r);
+        x.f1 = *reinterpret_cast<const f32x4*>(r + 4);
+    } else if constexpr (EPI == VDA_EPI_RES_F16) {
+        const size_t off = (size_t)m * p.ldc + n;
+        x.h0 = *reinterpret_cast<const h16x8*>((const h16*)p.res + off);
+        if (p.res2) x.h1 = *reinterpret_cast<const h16x8*>((const h16*)p.res2 + off);
+    } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
+        const int q = m % p.P;
+        x.f0 = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + q) * p.N + n);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n, float (&v)[8], float (&g)[8],
+                                            const ColConst<8>& c, const RowAux& x) {
+    if (m >= p.M || n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += c.bias[i];
+    if constexpr (EPI == VDA_EPI_BIAS_F16) {
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_RES_F16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += (float)x.h0[i];
+        if (p.res2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += (float)x.h1[i];
+        }
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = x.f0[i] + c.gamma[i] * v[i];
+            v[4 + i] = x.f1[i] + c.gamma[4 + i] * v[4 + i];
+        }
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+        // n is a VALUE column group (n % 32 < 16); g holds columns n+16.. (the gates)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf(g[i] + c.gbias[i]);
+        store8h((h16*)p.out + (size_t)m * p.ldc + ((n >> 5) * 16 + (n & 15)), v);
+    } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
+        const int k = p.tK, Co = p.tCout;
+        const int tap = n / Co, co = n - tap * Co;
+        const int ky = tap / k, kx = tap - ky * k;
+        const int hw = p.tH * p.tW;
+        const int b = m / hw, rem = m - b * hw;
+        const int y = rem / p.tW, xx = rem - y * p.tW;
+        const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)xx * k + kx;
+        store8h((h16*)p.out + orow * p.ldc + co, v);
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void finish_row4(const vda_gemm_args& p, int m, int n, f32x4 v, const ColConst<4>& c, const RowAux& x) {
+    if (m >= p.M || n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += c.bias[i];
+    if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = x.f0[i] + c.gamma[i] * v[i];
+        *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
+        *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
+    } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
+        const int f = m / p.P, q = m - f * p.P;
+        v += x.f0;
+        *reinterpret_cast<f32x4*>((float*)p.out + ((size_t)f * (p.P + 1) + 1 + q) * p.ldc + n) = v;
+    }
+}
+
+// Run `f(tag)` with the runtime epilogue id lifted to a compile-time constant.
+template <class F>
+__device__ __forceinline__ void dispatch_epilogue(int epilogue, F&& f) {
+    switch (epilogue) {
+        case VDA_EPI_BIAS_F16: f(std::integral_constant<int, VDA_EPI_BIAS_F16>{}); break;
+        case VDA_EPI_BIAS_GELU_F16: f(std::integral_constant<int, VDA_EPI_BIAS_GELU_F16>{}); break;
+        case VDA_EPI_BIAS_RELU_F16: f(std::integral_constant<int, VDA_EPI_BIAS_RELU_F16>{}); break;
+        case VDA_EPI_SCALE_RES_F32: f(std::integral_constant<int, VDA_EPI_SCALE_RES_F32>{}); break;
+        case VDA_EPI_RES_F16: f(std::integral_constant<int, VDA_EPI_RES_F16>{}); break;
+        case VDA_EPI_GEGLU_F16: f(std::integral_constant<int, VDA_EPI_GEGLU_F16>{}); break;
+        case VDA_EPI_PATCH_F32: f(std::integral_constant<int, VDA_EPI_PATCH_F32>{}); break;
+        case VDA_EPI_CONVT_F16: f(std::integral_constant<int, VDA_EPI_CONVT_F16>{}); break;
+        case VDA_EPI_BIAS_F32: f(std::integral_constant<int, VDA_EPI_BIAS_F32>{}); break;
+        case VDA_EPI_SCALE_RES_F32_H: f(std::integral_constant<int, VDA_EPI_SCALE_RES_F32_H>{}); break;
+        default: break;
+    }
+}
+
+}  // namespace vda_gemm

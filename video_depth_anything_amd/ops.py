@@ -8,8 +8,24 @@ import ctypes as C
 
 import torch
 
+import os
+import sys
+
 from . import _lib
-from ._lib import GemmArgs, check, lib
+from ._lib import GemmArgs, lib
+from ._lib import check as _check
+
+_TRACE = os.environ.get("VDA_TRACE_SYNC") == "1"     # debug: sync + log after every launch (finds a faulting kernel)
+
+
+def check(rc, what=""):
+    _check(rc, what)
+    if _TRACE:
+        sys.stderr.write(f"[vda] {what} ...")
+        sys.stderr.flush()
+        torch.cuda.synchronize()
+        sys.stderr.write(" ok\n")
+        sys.stderr.flush()
 
 F16, F32 = torch.float16, torch.float32
 
@@ -58,7 +74,7 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     a.ldc = N if ldc is None else ldc
     a.a_mode = _lib.A_DENSE if conv is None else _lib.A_CONV3X3
     a.epilogue = epi
-    a.relu_in = 1 if relu_in else 0
+    a.relu_in = int(relu_in)
     if conv is not None:
         a.cB, a.cH, a.cW, a.cCin, a.cHo, a.cWo, a.cStride = conv
     a.P = P
@@ -67,14 +83,14 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     if W.numel() < N * K:
         raise ValueError("W smaller than N*K")
     if PROFILE is None:
-        check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
+        check(lib.vda_gemm_f16(C.byref(a), _stream()),
+              f"vda_gemm_f16 M={M} N={N} K={K} epi={epi} conv={conv} lda={a.lda} ldc={a.ldc}" if _TRACE else "vda_gemm_f16")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
     e1.record()
-    name = "gemm_kernel<128,%d,%s>" % (64 if N <= 64 else 128, "dense" if conv is None else "conv3x3")
-    PROFILE.append((name, 2.0 * M * N * K, e0, e1))
+    PROFILE.append((lib.vda_gemm_last_kernel().decode(), 2.0 * M * N * K, e0, e1))
 
 
 def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
