@@ -280,13 +280,15 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     if (big) {
         const int rc = vda_gemm256_launch(a, big, s);
         if (rc >= 0) {
-            g_last_kernel = a.a_mode == VDA_A_DENSE ? (big == 256 ? "gemm256_kernel<256,dense>" : "gemm256_kernel<128,dense>")
-                                                    : (big == 256 ? "gemm256_kernel<256,conv3x3>" : "gemm256_kernel<128,conv3x3>");
+            // exact instantiation name as rocprofv3 prints it: gemm256_kernel<BN, a_mode, epilogue>
+            static thread_local char name[64];
+            snprintf(name, sizeof(name), "gemm256_kernel<%d, %d, %d>", big, a.a_mode, a.epilogue);
+            g_last_kernel = name;
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel
     }
-    g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128,64,dense>" : "gemm_kernel<128,128,dense>")
-                                            : (a.N <= 64 ? "gemm_kernel<128,64,conv3x3>" : "gemm_kernel<128,128,conv3x3>");
+    g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
+                                            : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
     const bool narrow = a.N <= 64;
     if (a.a_mode == VDA_A_DENSE) return narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
     return narrow ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
