@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
             }
         }
         // accumulator register e of half `sub` is key  kt*64 + sub*32 + (e&3) + 8*(e>>2) + 4h
-        if (kt == nt - 1 && (N % BKV) != 0) {
+        if (__builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0))) {      // scalar branch, last tile only
             const int kbase = kt * BKV + 4 * h;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -129,24 +129,35 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * LOG2E);
-        const float mb = m_new * LOG2E;
-        float psum = 0.f;
+        // Rescale only when some query's running max moved (alpha == 1 exactly otherwise, so skipping is bit-exact).
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(m_new > m_run) != 0ull))) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+            m_run = m_new;
+        }
+        // p = exp2(s*log2e - m*log2e) on float pairs (v_pk_fma_f32 / v_pk_add_f32); raw v_exp_f32: the argument
+        // is <= 0 and flushing tiny results to zero is harmless.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 mb2 = {m_run * LOG2E, m_run * LOG2E};
+        const f32x2 l2e = {LOG2E, LOG2E};
+        f32x2 ps2 = {0.f, 0.f};
         h16x8 pf[4];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float pv = exp2f(s[sub][e] * LOG2E - mb);
-                psum += pv;
-                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 a = {s[sub][e], s[sub][e + 1]};
+                a = a * l2e - mb2;
+                f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                ps2 += pv;
+                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv[0];
+                pf[sub * 2 + (e >> 3)][(e & 7) + 1] = (h16)pv[1];
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+        l_run += ps2[0] + ps2[1];
 
         // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
 #pragma unroll

@@ -7,61 +7,100 @@
 namespace {
 
 // ---------------------------------------------------------------- LayerNorm
-// One wave per row; a lane keeps up to MAXV float4 of the row in registers (D <= 64*4*MAXV).
-constexpr int LN_MAXV = 8;
+// A row is split over LPR lanes, 8 consecutive elements per lane per chunk (two 16-byte loads in, one 16-byte
+// store out); a wave holds 64/LPR rows, so small D (temporal modules: 64..256) still fills the wave. The row
+// stays in registers; statistics are fp32, two-pass (mean, then centred sum of squares). Cross-lane sums use
+// DPP (quad_perm / row_half_mirror / row_mirror) and v_readlane, not ds_bpermute: no LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_xchg(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
 
+template <int LPR>
+__device__ __forceinline__ float segment_sum(float v, int lane) {
+    v += dpp_xchg<0xB1>(v);                 // quad_perm [1,0,3,2]
+    v += dpp_xchg<0x4E>(v);                 // quad_perm [2,3,0,1]
+    v += dpp_xchg<0x141>(v);                // row_half_mirror: 8 lanes
+    if constexpr (LPR >= 16) v += dpp_xchg<0x140>(v);    // row_mirror: 16 lanes
+    if constexpr (LPR == 32) {
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+                         __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+        v = lane < 32 ? lo : hi;
+    }
+    if constexpr (LPR == 64) {
+        v = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+            (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+    }
+    return v;
+}
+
+template <int LPR, int NCH>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ in, h16* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, int rows, int D, int group, int skip,
                                                         const float* __restrict__ pe, int pe_rows_per_step, int pe_steps) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    constexpr int RPW = 64 / LPR;                                  // rows per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsel = lane / LPR;
+    const int row = (blockIdx.x * 4 + wave) * RPW + rsel;
+    const bool row_ok = row < rows;
+    const int nchunk = D >> 3;                                     // 8-element chunks per row
+    const float* src = in + (size_t)(row_ok ? row : 0) * D;
+    f32x4 v[NCH][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = sub + c * LPR;
+        const bool ok = row_ok && ch < nchunk;
+        v[c][0] = v[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            v[c][0] = *reinterpret_cast<const f32x4*>(src + ch * 8);
+            v[c][1] = *reinterpret_cast<const f32x4*>(src + ch * 8 + 4);
+        }
+        sum += ((v[c][0][0] + v[c][0][1]) + (v[c][0][2] + v[c][0][3])) + ((v[c][1][0] + v[c][1][1]) + (v[c][1][2] + v[c][1][3]));
+    }
+    const float mean = segment_sum<LPR>(sum, lane) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool ok = sub + c * LPR < nchunk;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = ok ? v[c][h][e] - mean : 0.f;
+                sq += d * d;
+            }
+    }
+    const float rstd = rsqrtf(segment_sum<LPR>(sq, lane) / (float)D + eps);
+    if (!row_ok) return;
     int orow = row;
     if (group > 0) {
         const int g = row / group, i = row - g * group;
-        if (i < skip) return;                                   // dropped row (cls token)
+        if (i < skip) return;                                       // dropped row (cls token)
         orow = g * (group - skip) + (i - skip);
     }
-    const int nv = D >> 2;                                      // float4 per row
-    const f32x4* src = reinterpret_cast<const f32x4*>(in + (size_t)row * D);
-    f32x4 v[LN_MAXV];
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int idx = lane + 64 * j;
-        if (idx < nv) {
-            v[j] = src[idx];
-            sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        }
-    }
-    const float mean = wave_sum(sum) / (float)D;
-    float sq = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int idx = lane + 64 * j;
-        if (idx < nv) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[j][e] - mean;
-                sq += d * d;
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
-    const float* per = nullptr;
-    if (pe) per = pe + (size_t)((row / pe_rows_per_step) % pe_steps) * D;
+    const float* per = pe ? pe + (size_t)((row / pe_rows_per_step) % pe_steps) * D : nullptr;
     h16* dst = out + (size_t)orow * D;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
-        const int idx = lane + 64 * j;
-        if (idx < nv) {
-            const f32x4 ww = reinterpret_cast<const f32x4*>(w)[idx];
-            const f32x4 bb = reinterpret_cast<const f32x4*>(b)[idx];
-            f32x4 y = (v[j] - mean) * rstd * ww + bb;
-            if (per) y += reinterpret_cast<const f32x4*>(per)[idx];
-            h16x4 o = {(h16)y[0], (h16)y[1], (h16)y[2], (h16)y[3]};
-            reinterpret_cast<h16x4*>(dst)[idx] = o;
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = sub + c * LPR;
+        if (ch < nchunk) {
+            h16x8 o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 ww = *reinterpret_cast<const f32x4*>(w + ch * 8 + h * 4);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b + ch * 8 + h * 4);
+                f32x4 y = (v[c][h] - mean) * rstd * ww + bb;
+                if (per) y += *reinterpret_cast<const f32x4*>(per + ch * 8 + h * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[h * 4 + e] = (h16)y[e];
+            }
+            *reinterpret_cast<h16x8*>(dst + ch * 8) = o;
         }
     }
 }
@@ -171,13 +210,24 @@ extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w,
                                      int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
                                      vda_stream_t stream) {
     VDA_REQUIRE(in && out && w && b, "vda_layernorm: null pointer");
-    VDA_REQUIRE(rows > 0 && D > 0 && D % 4 == 0 && D <= 64 * 4 * LN_MAXV, "vda_layernorm: D=%d must be a multiple of 4 and <= %d", D,
-                64 * 4 * LN_MAXV);
+    VDA_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048, "vda_layernorm: D=%d must be a multiple of 8 and <= 2048", D);
     VDA_REQUIRE(group == 0 || (group > 0 && skip >= 0 && skip < group && rows % group == 0), "vda_layernorm: bad group/skip");
     VDA_REQUIRE(pe == nullptr || (pe_rows_per_step > 0 && pe_steps > 0), "vda_layernorm: bad pe geometry");
-    VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0, "vda_layernorm: alignment");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, in, (h16*)out, w, b, eps, rows, D,
-                       group, skip, pe, pe_rows_per_step, pe_steps);
+    VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)b & 15) == 0 &&
+                    ((uintptr_t)pe & 15) == 0,
+                "vda_layernorm: 16-byte alignment required");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = D / 8;
+#define VDA_LN_LAUNCH(LPR, NCH)                                                                                               \
+    hipLaunchKernelGGL((layernorm_kernel<LPR, NCH>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, in, \
+                       (h16*)out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps)
+    if (nchunk <= 8) VDA_LN_LAUNCH(8, 1);
+    else if (nchunk <= 16) VDA_LN_LAUNCH(16, 1);
+    else if (nchunk <= 32) VDA_LN_LAUNCH(32, 1);
+    else if (nchunk <= 64) VDA_LN_LAUNCH(64, 1);
+    else if (nchunk <= 128) VDA_LN_LAUNCH(64, 2);
+    else VDA_LN_LAUNCH(64, 4);
+#undef VDA_LN_LAUNCH
     VDA_LAUNCH_CHECK();
     return 0;
 }
