@@ -111,6 +111,12 @@ def main():
             a[2] += flops
         dom = max(agg, key=lambda k: agg[k][1])
         calls, secs, flops = agg[dom]
+        # HBM bytes per launch of that kernel: cannot be read live (needs rocprofv3 --pmc passes); taken from the
+        # committed PMC summary of the same command (tools/pmc_bench.sh -> profiles/), null when absent.
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", f"{args.encoder}_pmc_hbm_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
         achieved = flops / secs / 1e12
         fps = world * args.steps * T / dt
         line = {
@@ -122,7 +128,7 @@ def main():
                                    f"(BASELINE.json configs[{2 if args.encoder == 'vitl' else 1}])",
                        "clips_per_step_per_gpu": 1, "parallelism": f"independent windows x{world}" + (", one all-gather of depth" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None, "launches": calls,
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": calls,
                          "avg_launch_us": secs / calls * 1e6, "algorithmic_gflop_per_launch": flops / calls / 1e9,
                          "share_of_step_time": secs / dt},
             "model_tflops": CLIP_TFLOP[args.encoder] * world * args.steps / dt,

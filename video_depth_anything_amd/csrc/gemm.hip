@@ -225,7 +225,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
                 "vda_gemm_f16: operands must be 16-byte aligned");
     VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_SCALE_RES_F32_H, "vda_gemm_f16: bad epilogue %d", a.epilogue);
     if (a.a_mode == VDA_A_DENSE) {
-        VDA_REQUIRE((a.relu_in & 1) == 0, "vda_gemm_f16: relu_in is only built for the conv A operand");
+        VDA_REQUIRE(a.relu_in == 0, "vda_gemm_f16: relu_in is only built for the conv A operand");
         VDA_REQUIRE((a.lda >= a.K || a.lda == 0) && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K (or 0 = broadcast row) and a multiple of 8", a.lda);
     } else if (a.a_mode == VDA_A_CONV3X3) {
         VDA_REQUIRE(a.zero_page != nullptr, "vda_gemm_f16: conv needs zero_page");
