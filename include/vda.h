@@ -134,6 +134,10 @@ int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out,
 /* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
  * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */
 int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream);
+/* Same, gathering frame idx[i] (device int32[n], each < n_video) of a uint8 video [n_video,H,W,3] resident in HBM:
+ * the window gather + key-frame refill of video_depth.py:197-201 without a host round trip. */
+int vda_gather_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H, int W,
+                                vda_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -309,6 +309,17 @@ def test_head_out_and_normalize(ops):
     np.testing.assert_array_equal(o.cpu().numpy(), ref)
 
 
+def test_gather_normalize_equals_normalize_of_gathered(ops):
+    rng = np.random.default_rng(6)
+    video = rng.integers(0, 256, (9, 14, 28, 3), dtype=np.uint8)
+    idx = [0, 8, 3, 3, 7]
+    a = torch.empty(5, 3, 14, 28, dtype=F32, device="cuda")
+    ops.gather_normalize_u8(torch.from_numpy(video).cuda(), torch.tensor(idx, dtype=torch.int32, device="cuda"), a, 5, 14, 28)
+    b = torch.empty(5, 3, 14, 28, dtype=F32, device="cuda")
+    ops.normalize_u8(torch.from_numpy(np.ascontiguousarray(video[idx])).cuda(), b, 5, 14, 28)
+    assert torch.equal(a, b)
+
+
 def test_refusals(ops):
     """Bad geometry is refused with a message, nothing is launched."""
     from video_depth_anything_amd import _lib

@@ -125,6 +125,23 @@ __global__ void __launch_bounds__(256) normalize_u8_kernel(const uint8_t* __rest
     }
 }
 
+// Same arithmetic as normalize_u8_kernel, but output frame i is source frame idx[i] of a video resident in HBM:
+// the window's gather (video_depth.py:197-201, key-frame refill included) without a host round trip.
+__global__ void __launch_bounds__(256) gather_normalize_u8_kernel(const uint8_t* __restrict__ f, const int* __restrict__ idx,
+                                                                  float* __restrict__ out, int n, int H, int W) {
+    const size_t hw = (size_t)H * W, total = (size_t)n * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t fr = i / hw, pix = i - fr * hw;
+        const uint8_t* p = f + ((size_t)idx[fr] * hw + pix) * 3;
+        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = (float)p[c] / 255.0f;
+            out[(fr * 3 + c) * hw + pix] = (float)(((double)v - mean[c]) / stdv[c]);
+        }
+    }
+}
+
 inline unsigned capped_grid(size_t work_items) {
     size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 16;
@@ -183,6 +200,15 @@ extern "C" int vda_head_out_f16_f32(const void* in, const float* w, float bias, 
 extern "C" int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream) {
     VDA_REQUIRE(frames && out && n > 0 && H > 0 && W > 0, "vda_normalize_u8: bad arguments");
     hipLaunchKernelGGL(normalize_u8_kernel, dim3(capped_grid((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, frames, out, n, H, W);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_gather_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H, int W,
+                                           vda_stream_t stream) {
+    VDA_REQUIRE(video && idx && out && n > 0 && n_video > 0 && H > 0 && W > 0, "vda_gather_normalize_u8: bad arguments");
+    hipLaunchKernelGGL(gather_normalize_u8_kernel, dim3(capped_grid((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, video,
+                       (const int*)idx, out, n, H, W);
     VDA_LAUNCH_CHECK();
     return 0;
 }

@@ -151,6 +151,13 @@ def normalize_u8(frames, out, n, H, W):
     check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream()), "vda_normalize_u8_f32")
 
 
+def gather_normalize_u8(video, idx, out, n, H, W):
+    _req(video, torch.uint8, "video"), _req(idx, torch.int32, "idx"), _req(out, F32, "out")
+    if idx.numel() < n or out.numel() < n * 3 * H * W:
+        raise ValueError("gather_normalize buffers too small")
+    check(lib.vda_gather_normalize_u8_f32(_p(video), _p(idx), _p(out), n, video.shape[0], H, W, _stream()), "vda_gather_normalize_u8_f32")
+
+
 # ---------------------------------------------------------------------------
 # Weight layouts the kernels expect (done once at load time, on the host or device)
 # ---------------------------------------------------------------------------

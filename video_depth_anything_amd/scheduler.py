@@ -122,9 +122,10 @@ def stitch_windows(window_depths: Sequence[np.ndarray], n_frames: int, metric: b
 
 
 # ------------------------------------------------------------------ driver (single or multi rank)
-def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray], metric: bool = False,
-                group=None) -> np.ndarray:
-    """Compute every window with `window_fn(frames_u8[32,H0,W0,3]) -> float32 [32,H0,W0]`, stitch.
+def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray] = None, metric: bool = False,
+                group=None, batch_fn: Callable[[List[List[int]]], List[np.ndarray]] = None) -> np.ndarray:
+    """Compute every window with `window_fn(frames_u8[32,H0,W0,3]) -> float32 [32,H0,W0]` (or, pipelined,
+    `batch_fn(list of 32-index lists) -> list of float32 [32,H0,W0]` over this rank's windows), stitch.
 
     With torch.distributed initialised (one process per GPU; NCCL == RCCL over xGMI, gloo on CPU),
     windows are block-partitioned over the ranks, there is no data-path collective while they are
@@ -138,7 +139,10 @@ def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
     mine = shard_windows(len(plan), world, rank)
-    local = [np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32) for k in mine]
+    if batch_fn is not None:
+        local = [np.ascontiguousarray(d, dtype=np.float32) for d in batch_fn([plan[k] for k in mine])]
+    else:
+        local = [np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32) for k in mine]
     if world == 1:
         return stitch_windows(local, n, metric)
 

@@ -71,21 +71,6 @@ class VideoDepthAnything:
     __call__ = forward
 
     # ---- video inference ---------------------------------------------------------------------
-    def _preprocess(self, frames_u8, H, W):
-        """uint8 [32,H0,W0,3] -> normalised fp32 [1,32,3,H,W] on the device."""
-        from . import ops
-        eng = self._ensure_engine()
-        n, H0, W0 = frames_u8.shape[:3]
-        dev_u8 = torch.from_numpy(np.ascontiguousarray(frames_u8)).to(eng.device, non_blocking=True)
-        x = torch.empty(1, n, 3, H0, W0, dtype=torch.float32, device=eng.device)
-        ops.normalize_u8(dev_u8, x, n, H0, W0)
-        if (H0, W0) != (H, W):
-            # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is not
-            # available offline, so this leg is PARITY UNPINNED: bicubic (a=-0.75, half-pixel centres) on
-            # the device; normalisation is affine so resizing after it is equivalent.
-            x = torch.nn.functional.interpolate(x[0], size=(H, W), mode='bicubic', align_corners=False)[None]
-        return x
-
     def infer_video_depth(self, frames, target_fps, input_size=518, device='cuda', fp32=False):
         global _FP32_WARNED
         if torch.device(device).type != 'cuda':
@@ -102,14 +87,45 @@ class VideoDepthAnything:
         H0, W0 = frames.shape[1:3]
         H, W = network_size(H0, W0, input_size)
 
-        def window_fn(win_u8):
-            x = self._preprocess(win_u8, H, W)
-            depth = eng.forward(x)                                           # [1,32,H,W] fp32
-            out = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=eng.device)
-            ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)   # video_depth.py:207-208
-            return out.cpu().numpy()                                         # one D2H per window
+        dev = eng.device
+        video = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)          # the whole uint8 video, uploaded ONCE
+        compute = torch.cuda.current_stream(dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+        pinned = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        dbuf = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)]
+        done = [torch.cuda.Event() for _ in range(2)]
+        xin = torch.empty(1, INFER_LEN, 3, H0, W0, dtype=torch.float32, device=dev)
 
-        depths = run_windows(frames, window_fn, metric=self.METRIC)
+        def batch_fn(index_lists):
+            """Windows of this rank, software-pipelined: window j's single D2H (pinned, side stream) overlaps window
+            j+1's gather/normalise/forward/resize on the compute stream."""
+            outs = []
+            for j, idxs in enumerate(index_lists):
+                s = j & 1
+                idx = torch.tensor(idxs, dtype=torch.int32, device=dev)
+                ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)      # video_depth.py:197-201 on the device
+                x = xin
+                if (H0, W0) != (H, W):
+                    # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is absent offline,
+                    # so this leg is PARITY UNPINNED: device bicubic (a=-0.75, half-pixel centres); normalisation is affine,
+                    # so resizing after it is equivalent.
+                    x = torch.nn.functional.interpolate(xin[0], size=(H, W), mode='bicubic', align_corners=False)[None]
+                depth = eng.forward(x)                                           # [1,32,H,W] fp32
+                ops.bilinear_plane(depth.view(INFER_LEN, H, W), dbuf[s], INFER_LEN, H, W, H0, W0)   # video_depth.py:207-208
+                copy_stream.wait_stream(compute)
+                with torch.cuda.stream(copy_stream):
+                    pinned[s].copy_(dbuf[s], non_blocking=True)                  # the window's ONE D2H
+                    done[s].record(copy_stream)
+                if j > 0:
+                    done[s ^ 1].synchronize()
+                    outs.append(pinned[s ^ 1].numpy().copy())
+            if index_lists:
+                last = (len(index_lists) - 1) & 1
+                done[last].synchronize()
+                outs.append(pinned[last].numpy().copy())
+            return outs
+
+        depths = run_windows(frames, metric=self.METRIC, batch_fn=batch_fn)
         return depths, target_fps
 
 
