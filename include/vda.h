@@ -76,7 +76,8 @@ typedef struct vda_gemm_args {
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
-/* Tuning hook: -1 (default) picks the tile per shape; 0 = 128-row tiles, 1 = 256x256, 2 = 256x128. */
+/* Tuning hook: -1 (default) picks the tile per shape; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 tiles on
+ * 32x32x16 MFMA; 3 / 4 = the same tiles on 16x16x32 MFMA (what -1 uses for wide N). */
 int vda_gemm_set_variant(int v);
 /* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
 const char* vda_gemm_last_kernel(void);

@@ -197,13 +197,23 @@ int vda_gemm256_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256_dense_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256_conv_bn128(const vda_gemm_args& a, hipStream_t s);
+// gemm256s_*.hip: the same tiles on v_mfma_f32_16x16x32_f16
+int vda_gemm256s_dense_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256s_dense_bn128(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256s_conv_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
+
+static int vda_gemm256s_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
+    if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256s_dense_bn256(a, s) : vda_gemm256s_dense_bn128(a, s);
+    return bn == 256 ? vda_gemm256s_conv_bn256(a, s) : vda_gemm256s_conv_bn128(a, s);
+}
 
 static int vda_gemm256_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
     if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256_dense_bn256(a, s) : vda_gemm256_dense_bn128(a, s);
     return bn == 256 ? vda_gemm256_conv_bn256(a, s) : vda_gemm256_conv_bn128(a, s);
 }
 
-static int g_gemm_variant = -1;   // -1 auto, 0 = 128-row tiles only, 1 = 256x256, 2 = 256x128 (tuning / A-B runs)
+static int g_gemm_variant = -1;   // tuning / A-B hook, see the dispatch in vda_gemm_f16
 
 static thread_local const char* g_last_kernel = "";
 
@@ -265,24 +275,28 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         if (a.a_mode == VDA_A_DENSE) return narrow0 ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
         return narrow0 ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
     }
-    int big = 0;
-    if (g_gemm_variant == 1) big = 256;
-    if (g_gemm_variant == 2) big = 128;
+    // variants: -1 auto; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 on 32x32x16 MFMA; 3 / 4 = the same on 16x16x32 MFMA
+    int big = 0, small_mfma = 1;
+    if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
+    if (g_gemm_variant == 2 || g_gemm_variant == 4) big = 128;
+    if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
     if (g_gemm_variant < 0 && a.N >= 192 && a.M >= 2048) {
         // large-tile kernel; BN picked for the smaller padded width
         const int pad256 = (a.N + 255) / 256 * 256, pad128 = (a.N + 127) / 128 * 128;
         big = pad128 < pad256 ? 128 : 256;
+        // measured (tools/gemm_bench.py): the 16x16x32 shape wins everywhere except the short-K in-place fp32 residual GEMM
+        if (a.epilogue == VDA_EPI_SCALE_RES_F32 && a.K <= 2048) small_mfma = 0;
     }
     if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
         VDA_REQUIRE(g_gemm_variant < 0, "vda_gemm_f16: the 256-row kernel needs N and ldc to be multiples of 8");
         big = 0;                            // its epilogue owns 8-column (16-byte) row segments
     }
     if (big) {
-        const int rc = vda_gemm256_launch(a, big, s);
+        const int rc = small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s);
         if (rc >= 0) {
-            // exact instantiation name as rocprofv3 prints it: gemm256_kernel<BN, a_mode, epilogue>
+            // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue>
             static thread_local char name[64];
-            snprintf(name, sizeof(name), "gemm256_kernel<%d, %d, %d>", big, a.a_mode, a.epilogue);
+            snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
             g_last_kernel = name;
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel

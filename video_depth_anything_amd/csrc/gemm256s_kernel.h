@@ -1,0 +1,344 @@
+// Large-tile fp16 MFMA GEMM / implicit-GEMM conv for gfx950: 256 x BN x 64 tiles, 8 waves, one
+// workgroup per CU. This is the kernel the encoder's qkv/proj/fc1/fc2 GEMMs and the head's wide convs run on.
+//
+// Why this shape: with a 128x128 tile every 32 MFMAs per wave need 32 KB staged from L2 into LDS; at MFMA
+// peak that is more than the L2 can deliver, so the small tile is staging-bound. 256x256 halves the staged
+// bytes per FLOP (64 KB per 64 MFMAs per wave) and the 128x64 wave tile cuts LDS fragment reads to
+// 0.75 ds_read_b128 per v_mfma_f32_32x32x16_f16.
+//
+// Pipeline (one __syncthreads per 64-deep K tile):
+//   LDS holds two K tiles (2 x 64 KB at BN=256). Fragments are register double-buffered at 16-deep k-step
+//   granularity: while the 8 MFMAs of step t issue, the 6 ds_read_b128 of step t+1 are in flight. The last
+//   step of tile k waits for tile k+1 (issued one whole tile earlier), barriers once, issues the 8
+//   global_load_lds of tile k+2 into the buffer tile k just vacated, and prefetches tile k+1's first
+//   fragments while its own MFMAs run, so the barrier never exposes an LDS or HBM round trip.
+//
+// LDS image: [rows][8 x 16 B], chunk ^= (row >> 1) & 7 (conflict-free for the 32-row ds_read_b128 fragment),
+// applied on the DMA SOURCE address and on the read address. MFMA operands are swapped (W rows as "A",
+// activation rows as "B") so a lane's accumulator registers are runs of 4 consecutive output columns.
+// 16x16x32-MFMA variant of gemm256_kernel.h (same tile, DMA, LDS image, persistence and epilogue; the K loop
+// is pipelined in units of 16 MFMAs: one 32-deep k step x half of the wave's rows).
+#pragma once
+#include "gemm_epilogue.h"
+
+namespace vda_gemm256s {
+
+constexpr int BK = 64;
+constexpr int ROW_BYTES = BK * 2;
+constexpr int BM = 256;
+constexpr int NW = 8;                 // waves
+constexpr int NT = NW * 64;
+
+template <int BN, int AMODE, int EPI>
+__global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
+    constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
+    constexpr int WM = NW / WN;                    // waves along M
+    constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile: 128x64 (BN=256) or 64x64 (BN=128)
+    constexpr int MI = WTM / 16, NJ = WTN / 16;    // 16x16 subtiles per wave
+    constexpr int MH = MI / 2;                       // subtiles per half of the wave's rows (pipeline unit)
+    constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;   // 1-KiB DMA pieces per wave
+    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + W_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // Persistent workgroups: one per CU, each walks tiles round by round. In round r the 32 workgroups of an
+    // XCD (equal bid % 8) take 32 CONSECUTIVE tiles (N fastest), so concurrently running tiles share A / W panels
+    // in that XCD's L2.
+    const int nbn = (p.N + BN - 1) / BN, nbm = (p.M + BM - 1) / BM;
+    const int ntiles = nbm * nbn;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int per_xcd = nwg >> 3;                                    // launch guarantees nwg % 8 == 0
+    auto tile_of = [&](int round) { return round * nwg + (bid & 7) * per_xcd + (bid >> 3); };
+
+    // ---- per-lane DMA sources. A piece is 8 rows x 128 B; lane -> (row lrow of the piece, LDS chunk lane & 7).
+    // The swizzled source chunk ((lane&7) ^ ((row>>1)&7)) does not depend on the piece index (pieces are 8 rows
+    // apart, the swizzle has period 16 rows and the wave stride is 64 rows), so it is one lane constant.
+    // Dense / W offsets are recomputed per K tile from the tile origin (3 VALU ops per piece) instead of being
+    // kept in registers; only the conv row decomposition (two divisions per piece) is cached.
+    const int lrow = lane >> 3;
+    const int src_chk = ((lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7)) * 8;     // halves
+    int a_pix[AJ], a_yx[AJ];          // conv: b*H*W, and (oy*stride-1) | (ox*stride-1) << 16
+    int tm0 = 0, tn0 = 0;             // origin of the tile being staged
+    auto set_sources = [&](int t) {
+        const int bm = t / nbn, bn = t - bm * nbn;
+        tm0 = bm * BM;
+        tn0 = bn * BN;
+        if constexpr (AMODE == VDA_A_CONV3X3) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                int m = tm0 + (wave + NW * j) * 8 + lrow;
+                const bool ok = m < p.M;
+                m = min(m, p.M - 1);
+                const int hw = p.cHo * p.cWo;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.cWo, ox = rem - oy * p.cWo;
+                a_pix[j] = b * p.cH * p.cW;
+                const int iy0 = ok ? oy * p.cStride - 1 : -20000, ix0 = ox * p.cStride - 1;
+                a_yx[j] = (iy0 & 0xffff) | (ix0 << 16);
+            }
+        }
+    };
+
+    auto stage = [&](int kt, char* buf) {
+        const int k0 = kt * BK;
+        if constexpr (AMODE == VDA_A_DENSE) {
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int m = min(tm0 + (wave + NW * j) * 8 + lrow, p.M - 1);
+                glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), buf + (wave + NW * j) * 1024);
+            }
+        } else {
+            const int tap = k0 / p.cCin, ci0 = k0 - tap * p.cCin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int j = 0; j < AJ; ++j) {
+                const int iy = (int)(short)(a_yx[j] & 0xffff) + ky, ix = (a_yx[j] >> 16) + kx;
+                const bool ok = (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
+                const h16* src = ok ? (const h16*)p.A + ((size_t)(a_pix[j] + iy * p.cW + ix) * p.cCin + ci0 + src_chk)
+                                    : (const h16*)p.zero_page + src_chk;
+                glds16(src, buf + (wave + NW * j) * 1024);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int n = min(tn0 + (wave + NW * j) * 8 + lrow, p.N - 1);
+            glds16((const h16*)p.W + (size_t)(unsigned)(n * p.K + src_chk + k0), buf + A_BYTES + (wave + NW * j) * 1024);
+        }
+    };
+
+    // fragment addressing: row = lane & 15 inside a 16-row subtile, k-chunk = 4*ks + (lane >> 4)
+    const int frow = lane & 15, fh = lane >> 4, fsw = (lane >> 1) & 7;     // ((row >> 1) & 7) with row = subtile*16 + frow
+    const int a_off = (wm * WTM + frow) * ROW_BYTES, w_off = A_BYTES + (wn * WTN + frow) * ROW_BYTES;
+    // relu on the activation operand (conv only), branch-free: max(x, 0) or max(x, -inf)
+    const h16 relu_floor = (p.relu_in & 1) ? (h16)0.f : (h16)(-65504.f);
+    h16x8 relu_thr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) relu_thr[e] = relu_floor;
+
+    struct AF {
+        h16x8 a[MH];
+    };
+    struct WF {
+        h16x8 w[NJ];
+    };
+    auto read_a = [&](const char* buf, int ks, int half, AF& f) {
+        const int coff = ((4 * ks + fh) ^ fsw) << 4;
+#pragma unroll
+        for (int i = 0; i < MH; ++i) f.a[i] = *reinterpret_cast<const h16x8*>(buf + a_off + (half * MH + i) * 16 * ROW_BYTES + coff);
+    };
+    auto read_w = [&](const char* buf, int ks, WF& f) {
+        const int coff = ((4 * ks + fh) ^ fsw) << 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) f.w[j] = *reinterpret_cast<const h16x8*>(buf + w_off + j * 16 * ROW_BYTES + coff);
+    };
+
+    const int nt = p.K / BK;
+    static_assert(WTN == 64, "epilogue staging assumes a 64-column wave tile");
+    // epilogue staging (8 waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
+    constexpr int STG_OFF = (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
+    char* stg = smem + STG_OFF + wave * 8192;
+
+    int tile = tile_of(0);
+    if (tile >= ntiles) return;                        // uniform per workgroup
+    set_sources(tile);
+    stage(0, smem);
+    for (int round = 0; tile < ntiles; ++round) {
+        const int bm = tile / nbn, bn = tile - bm * nbn;
+        const int m0 = bm * BM, n0 = bn * BN;
+
+        f32x4 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](int half, AF& fa, const WF& fw) {
+            if constexpr (AMODE == VDA_A_CONV3X3) {
+#pragma unroll
+                for (int i = 0; i < MH; ++i) fa.a[i] = __builtin_elementwise_max(fa.a[i], relu_thr);
+            }
+#pragma unroll
+            for (int i = 0; i < MH; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if (half == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[i][j], 0, 0, 0);
+                    else acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[MH + i][j], 0, 0, 0);
+                }
+        };
+
+        // K tile 0 of this tile was issued before the previous tile's epilogue (or above, for the first tile).
+        AF a0, a1;
+        WF w0, w1;
+        if (round > 0) set_sources(tile);       // recomputed rather than kept live across the epilogue
+        // Full barrier (with its fences, so no LDS read can be scheduled above it): K tile 0 has landed everywhere.
+        // K tile 1 is issued after it and has the whole of K tile 0's MFMA work to land, as in the steady state.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nt > 1) stage(1, smem + STAGE);
+        read_w(smem, 0, w0);
+        read_a(smem, 0, 0, a0);
+        for (int kt = 0; kt < nt; ++kt) {
+            char* cb = smem + (kt & 1) * STAGE;
+            char* nb = smem + ((kt + 1) & 1) * STAGE;
+            read_a(cb, 0, 1, a1);
+            read_w(cb, 1, w1);
+            mma(0, a0, w0);
+            read_a(cb, 1, 0, a0);
+            mma(1, a1, w0);
+            read_a(cb, 1, 1, a1);
+            mma(0, a0, w1);
+            // Tile kt+1 must have landed everywhere and every wave must be done READING tile kt (its last fragments
+            // are already in a1 / w1 once lgkmcnt drains): one full barrier per K tile, explicit DMA drain first.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 2 < nt) stage(kt + 2, cb);
+            if (kt + 1 < nt) {
+                read_w(nb, 0, w0);
+                read_a(nb, 0, 0, a0);
+            }
+            mma(1, a1, w1);
+        }
+        // After the loop's last barrier nobody reads the pipeline buffers any more: start the NEXT tile's first
+        // K tile now, so its HBM/L2 latency is covered by this tile's epilogue.
+        const int next = tile_of(round + 1);
+        if (next < ntiles) {
+            set_sources(next);
+            stage(0, smem);
+        }
+
+        // ---- epilogue. Accumulator register e of subtile (i,j) is row m = lane & 31, column 8*(e>>2) + 4*(lane>>5) + (e&3):
+        // stored straight from this layout a wave instruction would touch 32 rows x 16 B (32 partial lines). Instead each
+        // wave transposes one 32-row x 64-column fp32 block at a time through its own 8 KiB of (idle) pipeline buffer 1
+        // (16-byte chunks XOR-swizzled by row: conflict-free both ways) and then owns whole row segments: bias / LayerScale /
+        // residual reads and the output stores become contiguous 16-byte accesses covering full 128-byte lines.
+        const int bm0 = m0 + wm * WTM, bn0 = n0 + wn * WTN;
+        {
+            using RT = vda_gemm::RowTraits<EPI>;
+            constexpr int NC = RT::NC, RR = RT::f32_out ? 8 : 4;            // columns per lane, row groups per 32-row block
+            // lane -> (row inside a group, column block): fp32 out: 4 rows x 16 lanes x 4 cols; fp16 out: 8 rows x 8 lanes x 8 cols
+            const int lrow_e = RT::f32_out ? (lane >> 4) : (lane >> 3);
+            const int c0 = RT::f32_out ? (lane & 15) : 2 * (lane & 7);      // first 16-byte (4-column) chunk of the lane
+            const int en = bn0 + c0 * 4;
+            const bool geglu_idle = (EPI == VDA_EPI_GEGLU_F16) && (c0 & 7) >= 4;   // gate lanes only feed their value lanes
+            vda_gemm::ColConst<NC> cc;
+            vda_gemm::load_col_const<EPI, NC>(p, en, cc);
+#pragma unroll
+            for (int i = 0; i < MI / 2; ++i) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        // accumulator (mi = 2i+h2, nj = j): row = h2*16 + (lane & 15) of the 32-row block, columns 16j + 4*(lane>>4) + e
+                        const int row = h2 * 16 + (lane & 15), c = j * 4 + (lane >> 4);
+                        *reinterpret_cast<f32x4*>(stg + row * 256 + ((c ^ (row & 15)) << 4)) = acc[2 * i + h2][j];
+                    }
+                // The transposition is a cross-LANE exchange inside one wave: the hardware runs a wave's LDS ops in order,
+                // but the compiler must not reorder the reads below across the writes above (it only reasons per thread).
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // Row groups are processed RG at a time: phase 1 issues every row-dependent global load of the group,
+                // phase 2 reads the transposed accumulators back, finishes and stores.
+                constexpr int RG = RT::f32_out ? 4 : 2;
+#pragma unroll
+                for (int r0 = 0; r0 < RR; r0 += RG) {
+                    vda_gemm::RowAux aux[RG];
+                    if (!geglu_idle) {
+#pragma unroll
+                        for (int q = 0; q < RG; ++q)
+                            vda_gemm::load_row_aux<EPI>(p, bm0 + i * 32 + (r0 + q) * (32 / RR) + lrow_e, en, aux[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < RG; ++q) {
+                        const int row = (r0 + q) * (32 / RR) + lrow_e;
+                        const char* rp = stg + row * 256;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(rp + ((c0 ^ (row & 15)) << 4));
+                        if constexpr (RT::f32_out) {
+                            vda_gemm::finish_row4<EPI>(p, bm0 + i * 32 + row, en, a, cc, aux[q]);
+                        } else {
+                            const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((c0 + 1) ^ (row & 15)) << 4));
+                            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                            float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+                                const f32x4 ga = *reinterpret_cast<const f32x4*>(rp + (((c0 + 4) & 15) ^ (row & 15)) * 16);
+                                const f32x4 gb = *reinterpret_cast<const f32x4*>(rp + (((c0 + 5) & 15) ^ (row & 15)) * 16);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    gt[e] = ga[e];
+                                    gt[4 + e] = gb[e];
+                                }
+                            }
+                            if (!geglu_idle) vda_gemm::finish_row8<EPI>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[q]);
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
+            }
+        }
+        // Every wave is done with its staging slice before the next tile's stage(1) overwrites buffer 1.
+        __syncthreads();
+        tile = next;
+    }
+}
+
+template <int BN, int AMODE, int EPI>
+int launch256(const vda_gemm_args& a, hipStream_t s) {
+    constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
+    constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + 8 * 8192;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    static int num_cu = 0;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return 2;
+        }
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (num_cu < 8) num_cu = 8;
+        num_cu &= ~7;                           // the XCD grouping wants a multiple of 8 workgroups
+        attr_set = true;
+    }
+    const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
+    const int ntiles = nbm * nbn;
+    const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
+    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI>), dim3(grid), dim3(NT), smem, s, a);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Dense A: every epilogue. Conv A: the three the head uses.
+template <int BN>
+int launch_dense(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F16>(a, s);
+        case VDA_EPI_BIAS_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_GELU_F16>(a, s);
+        case VDA_EPI_BIAS_RELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_RELU_F16>(a, s);
+        case VDA_EPI_SCALE_RES_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32>(a, s);
+        case VDA_EPI_RES_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_RES_F16>(a, s);
+        case VDA_EPI_GEGLU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_GEGLU_F16>(a, s);
+        case VDA_EPI_PATCH_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_PATCH_F32>(a, s);
+        case VDA_EPI_CONVT_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_CONVT_F16>(a, s);
+        case VDA_EPI_BIAS_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F32>(a, s);
+        case VDA_EPI_SCALE_RES_F32_H: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32_H>(a, s);
+        default: break;
+    }
+    return -1;
+}
+
+template <int BN>
+int launch_conv(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_CONV3X3, VDA_EPI_BIAS_F16>(a, s);
+        case VDA_EPI_BIAS_RELU_F16: return launch256<BN, VDA_A_CONV3X3, VDA_EPI_BIAS_RELU_F16>(a, s);
+        case VDA_EPI_RES_F16: return launch256<BN, VDA_A_CONV3X3, VDA_EPI_RES_F16>(a, s);
+        default: break;
+    }
+    return -1;                                  // caller falls back to the 128-row kernel
+}
+
+}  // namespace vda_gemm256s

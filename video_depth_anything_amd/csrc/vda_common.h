@@ -35,7 +35,22 @@ extern "C" void vda_set_error(const char* fmt, ...);
         }                                                              \
     } while (0)
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) (nn.GELU() default, dinov2.py:61; F.gelu, motion_module/attention.py:378).
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output rounding): one v_rcp, one v_exp and
+// six FMAs instead of libm erff's ~30 instructions - the GELU epilogue runs 128x per lane per GEMM tile.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.4426950408889634f);
+    const float r = fmaf(-p, e, 1.0f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 
 // 16-byte async global -> LDS copy. The LDS destination is the wave-uniform `lds_base`
 // plus lane*16 (hardware rule); the global source is per lane.
