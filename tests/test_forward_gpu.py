@@ -132,6 +132,34 @@ def test_oracle_vits_4frames_518():
     assert e < TOL_DEPTH, f"rel-L1 {e}"
 
 
+def test_oracle_vitl_2frames_518():
+    """The headline model: ViT-L, 2 frames at 518x518, HIP path vs the CPU oracle (fp32)."""
+    from oracle import vda_oracle as O
+    m, cfg, sd = model_for("vitl", 3)
+    x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(72))
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, x).numpy()
+    d = m(x.cuda()).cpu().numpy()
+    e = rel_l1(d, ref)
+    record("vitl.2x518.depth_vs_oracle", e)
+    assert e < TOL_DEPTH, f"rel-L1 {e}"
+
+
+def test_run_cli_synthetic(tmp_path):
+    """run.py end to end with the reference's flags: frames from .npz, depths to <name>_depths.npz."""
+    import subprocess
+    import sys
+    frames = np.random.default_rng(9).integers(0, 256, (30, 70, 84, 3), dtype=np.uint8)
+    src = tmp_path / "clip.npz"
+    np.savez(src, frames=frames, fps=24)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "run.py"), "--input_video", str(src), "--output_dir", str(tmp_path / "out"),
+                        "--encoder", "vits", "--input_size", "70", "--checkpoint", "synthetic", "--save_npz"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = np.load(tmp_path / "out" / "clip_depths.npz")["depths"]
+    assert d.shape == (30, 70, 84) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0
+
+
 def test_batch_of_clips_equals_separate_clips():
     m, _, _ = model_for("vits", 8)
     x = torch.randn(2, 5, 3, 70, 84, generator=torch.Generator().manual_seed(71)).cuda()
