@@ -15,36 +15,39 @@ __device__ __forceinline__ void lerp_coord(int dst, int in, int outn, int& i0, i
     w1 = src - (float)i0;
 }
 
+// Block = one output row (b, Y): the row's two source rows and vertical weight are block constants, a thread walks
+// (X, 8-channel vector) pairs with 32-bit index math only (the flat-index version spent its time in 64-bit div/mod).
 __global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const h16* __restrict__ in, h16* __restrict__ out,
                                                             const h16* __restrict__ add, int B, int h, int w, int H, int W, int C) {
     const int nv = C >> 3;
-    const size_t total = (size_t)B * H * W * nv;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int v = (int)(idx % nv);
-        size_t pix = idx / nv;
-        const int X = (int)(pix % W);
-        pix /= W;
-        const int Y = (int)(pix % H);
-        const int b = (int)(pix / H);
-        int y0, y1, x0, x1;
-        float wy, wx;
-        lerp_coord(Y, h, H, y0, y1, wy);
-        lerp_coord(X, w, W, x0, x1, wx);
-        const h16* base = in + (size_t)b * h * w * C + v * 8;
-        const h16x8 a00 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * w + x0) * C);
-        const h16x8 a01 = *reinterpret_cast<const h16x8*>(base + ((size_t)y0 * w + x1) * C);
-        const h16x8 a10 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * w + x0) * C);
-        const h16x8 a11 = *reinterpret_cast<const h16x8*>(base + ((size_t)y1 * w + x1) * C);
-        h16x8 o;
+    const int Y = blockIdx.x, b = blockIdx.y;
+    int y0, y1;
+    float wy;
+    lerp_coord(Y, h, H, y0, y1, wy);
+    const h16* r0 = in + ((size_t)b * h + y0) * w * C;
+    const h16* r1 = in + ((size_t)b * h + y1) * w * C;
+    const size_t orow = ((size_t)b * H + Y) * W * C;
+    const float xscale = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const int n = W * nv;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int X = i / nv, v = i - X * nv;
+        const float src = xscale * (float)X;
+        const int x0 = min((int)src, w - 1), x1 = min(x0 + 1, w - 1);
+        const float wx = src - (float)x0;
+        const h16x8 a00 = *reinterpret_cast<const h16x8*>(r0 + x0 * C + v * 8);
+        const h16x8 a01 = *reinterpret_cast<const h16x8*>(r0 + x1 * C + v * 8);
+        const h16x8 a10 = *reinterpret_cast<const h16x8*>(r1 + x0 * C + v * 8);
+        const h16x8 a11 = *reinterpret_cast<const h16x8*>(r1 + x1 * C + v * 8);
         h16x8 ad = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (add) ad = *reinterpret_cast<const h16x8*>(add + idx * 8);
+        if (add) ad = *reinterpret_cast<const h16x8*>(add + orow + (size_t)i * 8);
+        h16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float top = (float)a00[e] * (1.f - wx) + (float)a01[e] * wx;
             const float bot = (float)a10[e] * (1.f - wx) + (float)a11[e] * wx;
             o[e] = (h16)(top * (1.f - wy) + bot * wy + (float)ad[e]);
         }
-        *reinterpret_cast<h16x8*>(out + idx * 8) = o;
+        *reinterpret_cast<h16x8*>(out + orow + (size_t)i * 8) = o;
     }
 }
 
@@ -155,8 +158,8 @@ extern "C" int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add,
     VDA_REQUIRE(in && out, "vda_bilinear_nhwc: null pointer");
     VDA_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "vda_bilinear_nhwc: bad geometry");
     VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)add & 15) == 0, "vda_bilinear_nhwc: alignment");
-    const size_t total = (size_t)B * H * W * (C / 8);
-    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(capped_grid(total)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out,
+    VDA_REQUIRE(B <= 65535 && (long long)w * C < (1ll << 31) && (long long)W * C < (1ll << 31), "vda_bilinear_nhwc: row too large");
+    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out,
                        (const h16*)add, B, h, w, H, W, C);
     VDA_LAUNCH_CHECK();
     return 0;
