@@ -132,6 +132,12 @@ int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int 
  * -> fp32 [rows] (dpt.py:121-122). */
 int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream);
 
+/* Fused depth tail (dpt.py:118-122, dpt_temporal.py:93-100, video_depth.py:162-163): NHWC fp16 [B,h,w,C] ->
+ * [bilinear align_corners resize to H x W when (h,w) != (H,W)] -> 3x3 conv C->32 (+b2, ReLU) -> 1x1 conv 32->1 (+b3, ReLU)
+ * -> fp32 [B,H,W]. w2: fp16 [32, 9*C] with K ordered (ky,kx,ci); C a multiple of 64; zero_page: >= 256 B of zeros. */
+int vda_depth_tail_f16(const void* in, const void* w2, const float* b2, const float* w3, float b3, float* out,
+                       const void* zero_page, int B, int h, int w, int H, int W, int C, vda_stream_t stream);
+
 /* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
  * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */
 int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream);

@@ -160,6 +160,26 @@ def test_run_cli_synthetic(tmp_path):
     assert d.shape == (30, 70, 84) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0
 
 
+def test_benchmark_infer_driver(tmp_path):
+    """benchmark/infer/infer.py: JSON manifest of scenes -> one float32 .npy per frame (frames supplied as .npy images)."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(10)
+    scene = []
+    os.makedirs(tmp_path / "data" / "scene0", exist_ok=True)
+    for i in range(5):
+        np.save(tmp_path / "data" / "scene0" / f"{i:03d}.npy", rng.integers(0, 256, (70, 84, 3), dtype=np.uint8))
+        scene.append({"image": f"data/scene0/{i:03d}.npy"})
+    man = tmp_path / "manifest.json"
+    man.write_text(json.dumps({"toy": [{"scene0": scene}]}))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "benchmark", "infer", "infer.py"), "--json_file", str(man), "--infer_path",
+                        str(tmp_path / "pred"), "--datasets", "toy", "--encoder", "vits", "--input_size", "70", "--checkpoint", "synthetic"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = np.load(tmp_path / "pred" / "toy" / "data" / "scene0" / "003.npy")
+    assert d.shape == (70, 84) and d.dtype == np.float32 and np.isfinite(d).all()
+
+
 def test_batch_of_clips_equals_separate_clips():
     m, _, _ = model_for("vits", 8)
     x = torch.randn(2, 5, 3, 70, 84, generator=torch.Generator().manual_seed(71)).cuda()

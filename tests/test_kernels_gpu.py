@@ -309,6 +309,23 @@ def test_head_out_and_normalize(ops):
     np.testing.assert_array_equal(o.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("Cc,h,w_,H,W_", [(64, 20, 37, 20, 37), (128, 9, 33, 9, 33), (64, 12, 12, 21, 21), (128, 17, 19, 29, 45)])
+def test_depth_tail(ops, Cc, h, w_, H, W_):
+    """Fused tail vs F.interpolate -> conv3x3 -> relu -> conv1x1 -> relu (same-size = no resize)."""
+    B = 2
+    x = rnd(B, Cc, h, w_, seed=70).to(F16)
+    w2, b2 = rnd(32, Cc, 3, 3, seed=71, scale=(9 * Cc) ** -0.5), rnd(32, seed=72)
+    w3, b3 = rnd(32, seed=73, scale=0.3), 0.4
+    out = torch.full((B, H, W_), float("nan"), dtype=F32, device="cuda")
+    ops.depth_tail(dev(x.permute(0, 2, 3, 1).contiguous()), dev(ops.pack_conv3x3(w2)), dev(b2), dev(w3), b3, out, B, h, w_, H, W_, Cc)
+    up = x.float()
+    if (h, w_) != (H, W_):
+        up = F.interpolate(up, size=(H, W_), mode="bilinear", align_corners=True).to(F16).float()
+    y = F.relu(F.conv2d(up, w2.to(F16).float(), b2, padding=1))
+    ref = F.relu((y * w3.view(1, 32, 1, 1)).sum(1) + b3)
+    close(out, ref, rtol=2e-3, atol=3e-3, what="depth tail")
+
+
 def test_gather_normalize_equals_normalize_of_gathered(ops):
     rng = np.random.default_rng(6)
     video = rng.integers(0, 256, (9, 14, 28, 3), dtype=np.uint8)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vda_patchify_f32_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_cls_rows_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "vda_head_out_f16_f32": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
+    "vda_depth_tail_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_normalize_u8_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_gather_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }

@@ -329,12 +329,10 @@ class Engine:
         hh, ww = 2 * h1, 2 * w1
         o1 = self.buf("o1", (BT * hh * ww, Fhp), F16)
         self.conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, _lib.EPI_BIAS_F16, bias=w["oc1.b"])
-        up = self.buf("up", (BT * H * W, Fhp), F16)
-        ops.bilinear_nhwc(o1, up, BT, hh, ww, H, W, Fhp)
-        o2 = self.buf("o2", (BT * H * W, 32), F16)
-        self.conv3x3(up, "oc2.w", o2, BT, H, W, Fhp, 32, _lib.EPI_BIAS_RELU_F16, bias=w["oc2.b"])
+        # bilinear to (H,W) + output_conv2 (3x3 -> ReLU -> 1x1 -> ReLU) in one kernel: the 518^2 x F/2 upsampled tensor is
+        # never materialised (dpt_temporal.py:94-100)
         depth = torch.empty(B, T, H, W, dtype=F32, device=self.device)
-        ops.head_out(o2, w["oc3.w"], self.oc3_bias, depth, BT * H * W, 32)
+        ops.depth_tail(o1, w["oc2.w"], w["oc2.b"], w["oc3.w"], self.oc3_bias, depth, BT, hh, ww, H, W, Fhp)
         # video_depth.py:162-163: bilinear to (H,W) is the identity here (H == 14*ph) and the ReLU is idempotent.
         if stages is not None:
             stages.update(layer_1=(l1, h1, w1, ocp[0]), layer_2=(l2, h2, w2, ocp[1]), layer_3=(l3, ph, pw, ocp[2]),

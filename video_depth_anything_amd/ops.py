@@ -146,6 +146,15 @@ def head_out(x, w, bias, out, rows, Cpad):
     check(lib.vda_head_out_f16_f32(_p(x), _p(w), float(bias), _p(out), rows, Cpad, _stream()), "vda_head_out_f16_f32")
 
 
+def depth_tail(x, w2, b2, w3, b3, out, B, h, w, H, W, Cc):
+    """[resize h x w -> H x W] + conv3x3(C->32)+ReLU + conv1x1(32->1)+ReLU, NHWC fp16 in, fp32 [B,H,W] out."""
+    _req(x, F16, "x"), _req(w2, F16, "w2"), _req(b2, F32, "b2"), _req(w3, F32, "w3"), _req(out, F32, "out")
+    if x.numel() < B * h * w * Cc or out.numel() < B * H * W or w2.numel() < 32 * 9 * Cc:
+        raise ValueError("depth_tail buffers too small")
+    check(lib.vda_depth_tail_f16(_p(x), _p(w2), _p(b2), _p(w3), float(b3), _p(out), _p(zero_page(x.device)), B, h, w, H, W, Cc,
+                                 _stream()), "vda_depth_tail_f16")
+
+
 def normalize_u8(frames, out, n, H, W):
     _req(frames, torch.uint8, "frames"), _req(out, F32, "out")
     check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream()), "vda_normalize_u8_f32")
