@@ -4,16 +4,23 @@
 // times through L2 to feed a 32-wide output (staging-bound, 290 TFLOP/s, plus a 2.2 GB upsampled tensor written
 // and read back); here a workgroup keeps the (8+2) x (32+2) pixel patch it needs in LDS and forms all nine taps from it.
 //
-//   workgroup = 8 x 32 output pixels, 4 waves; a wave owns 2 rows = two 32-pixel MFMA column blocks
-//   patch in LDS: [pixel][64 channels] per 64-channel pass (128 B rows, 16-byte chunks XOR-swizzled by (pixel>>1)&7:
-//                 conflict-free for the 32-consecutive-pixel ds_read_b128 fragment at any offset)
-//   patch fill:   SRC_UP = 0: 16-byte LDS-DMA straight from the tensor (zero page outside the image = conv padding)
-//                 SRC_UP = 1: the bilinear resize is evaluated here from the low-res tensor and written with
-//                             ds_write_b128 - the upsampled tensor never exists in memory
-//   MFMA:         v_mfma_f32_32x32x16_f16, A = weights [32 cout][16 k] from L2 (72 KiB, every workgroup reads the same),
-//                 B = patch [16 k][32 pixels]; D[cout][pixel]: a lane owns one pixel and 16 of its 32 couts
-//   epilogue:     bias + ReLU, dot with the 32->1 weights in-lane + one lane^32 exchange, bias + ReLU, fp32 store
-//                 (32 consecutive pixels per store instruction = full 128-byte lines)
+//   workgroup = 8 x 32 output pixels, 4 waves; a wave owns 2 output rows = two 32-pixel MFMA column blocks
+//   pass      = 32 input channels: LDS holds the patch [340 pixels][32 ch] and the weights [9 taps x 32 cout][32 ch]
+//               (64-byte rows; 16-byte chunks XOR-swizzled by (row >> 1) & 3: any 16 consecutive rows of one chunk
+//               cover the eight 16-byte bank groups exactly twice = conflict-free ds_read_b128). 40 KiB -> 3 workgroups
+//               per CU, so one workgroup's fill overlaps its neighbours' MFMA phase.
+//   weights   : LDS-DMA per pass (L2 -> LDS, 18 KiB). Re-reading them from L2 per MFMA made v1 L2-bandwidth-bound.
+//   patch fill: SRC_UP = 0: 16-byte LDS-DMA straight from the tensor (zero page outside the image = conv padding)
+//               SRC_UP = 1: the bilinear resize is evaluated here: 4 gathers from the low-res tensor (offsets and
+//                           weights precomputed once per workgroup), packed-fp16 lerp, ds_write_b128 - the
+//                           upsampled tensor never exists in memory
+//   MFMA      : v_mfma_f32_32x32x16_f16, A = weights [32 cout][16 k], B = patch [16 k][32 pixels]; D[cout][pixel].
+//               Patch row R serves (output row R, ky=0), (R-1, ky=1), (R-2, ky=2): per (kx, k-step) a wave reads
+//               4 patch-row fragments + 3 weight fragments for 6 MFMAs.
+//   epilogue  : bias + ReLU, dot with the 32->1 weights in-lane + one lane^32 exchange, bias + ReLU, fp32 store
+//               (32 consecutive pixels per store instruction = full 128-byte lines)
+//   launch    : 1-D grid, workgroup id -> tile remapped so that the workgroups of one XCD take consecutive tiles
+//               (neighbouring tiles share halo / source pixels in that XCD's L2).
 #include "vda_common.h"
 
 namespace {
@@ -21,20 +28,48 @@ namespace {
 constexpr int TH = 8, TW = 32;                 // output tile
 constexpr int PH = TH + 2, PW = TW + 2;        // patch with halo
 constexpr int NPIX = PH * PW;                  // 340
-constexpr int NPIECE = (NPIX + 7) / 8;         // 1-KiB DMA pieces (8 pixels x 128 B) per pass
-constexpr int CC = 64;                         // channels per pass
-constexpr int PATCH_BYTES = NPIECE * 1024;
+constexpr int CC = 32;                         // channels per pass
+constexpr int ROWB = CC * 2;                   // 64-byte LDS rows
+constexpr int NP_PATCH = (NPIX + 15) / 16;     // 1-KiB DMA pieces (16 rows x 64 B)
+constexpr int PATCH_BYTES = NP_PATCH * 1024;
+constexpr int NP_W = 9 * 32 / 16;
+constexpr int W_BYTES = NP_W * 1024;
+constexpr int NK = (NPIX + 63) / 64;           // bilinear items per thread and pass
 
-__device__ __forceinline__ int p_swz(int q) { return (q >> 1) & 7; }
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int swz(int r) { return (r >> 1) & 3; }
+
+// a + (b - a) * w on 8 halfs as four v_pk_add_f16 + four v_pk_fma_f16 (w = one VGPR holding the weight twice)
+__device__ __forceinline__ h16x8 lerp8(const h16x8 a, const h16x8 b, const h16x2 w) {
+    h16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const h16x2 av = {a[2 * i], a[2 * i + 1]}, bv = {b[2 * i], b[2 * i + 1]};
+        const h16x2 o = av + (bv - av) * w;
+        r[2 * i] = o[0];
+        r[2 * i + 1] = o[1];
+    }
+    return r;
+}
 
 template <int SRC_UP>
-__global__ void __launch_bounds__(256) depth_tail_kernel(const h16* __restrict__ in, const h16* __restrict__ w2, const float* __restrict__ b2,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) depth_tail_kernel(const h16* __restrict__ in, const h16* __restrict__ w2, const float* __restrict__ b2,
                                                          const float* __restrict__ w3, float b3, float* __restrict__ out,
-                                                         const h16* __restrict__ zero_page, int h, int w, int H, int W, int C) {
-    __shared__ __attribute__((aligned(16))) char patch[PATCH_BYTES];
+                                                         const h16* __restrict__ zero_page, int h, int w, int H, int W, int C, int tiles_x,
+                                                         int tiles_y, int ntiles) {
+    __shared__ __attribute__((aligned(16))) char lds[PATCH_BYTES + W_BYTES];
+    char* const patch = lds;
+    char* const wl = lds + PATCH_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    // workgroups are dealt to the 8 XCDs round-robin: give XCD x the contiguous tile range [x * per_xcd, (x+1) * per_xcd)
+    const int per_xcd = gridDim.x >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;                               // uniform per workgroup
+    const int tx = tile % tiles_x, tyb = tile / tiles_x;
+    const int ty = tyb % tiles_y, b = tyb / tiles_y;
+    const int x0 = tx * TW, y0 = ty * TH;
     const int px = lane & 31, hh = lane >> 5;
 
     f32x16 acc[2];
@@ -43,66 +78,104 @@ __global__ void __launch_bounds__(256) depth_tail_kernel(const h16* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
-    const float ys = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, xs = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    // ---- bilinear (align_corners=True) geometry of this thread's patch pixels: the same for every pass
+    const int ch = tid & 3;                                   // 16-byte chunk (8 channels) of the pass
+    int off00[NK], dxo[NK], dyo[NK];                          // halfs: (ya, xa) corner, +1 column, +1 row; off00 < 0 = outside the image
+    h16x2 wxh[NK], wyh[NK];                                   // the lerp weight in both halves of one VGPR
+    if constexpr (SRC_UP == 1) {
+        const float ys = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, xs = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int q = (tid >> 2) + 64 * k;
+            const int py = q / PW, pxx = q - py * PW;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            const bool ok = q < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const float sy = ys * (float)iy, sx = xs * (float)ix;
+            const int ya = max(min((int)sy, h - 1), 0), yb = min(ya + 1, h - 1);
+            const int xa = max(min((int)sx, w - 1), 0), xb = min(xa + 1, w - 1);
+            off00[k] = ok ? ((b * h + ya) * w + xa) * C + ch * 8 : -1;
+            dxo[k] = ok ? (xb - xa) * C : 0;
+            dyo[k] = ok ? (yb - ya) * w * C : 0;
+            const h16 wx = (h16)(sx - (float)xa), wy = (h16)(sy - (float)ya);
+            wxh[k] = h16x2{wx, wx};
+            wyh[k] = h16x2{wy, wy};
+        }
+    }
 
     for (int c0 = 0; c0 < C; c0 += CC) {
-        if (c0 > 0) __syncthreads();                         // everyone done reading the previous pass's patch
-        // ---- fill the patch for channels c0 .. c0+63
+        if (c0 > 0) __syncthreads();                         // everyone done reading the previous pass's patch / weights
+        // ---- weights of this pass: rows R = tap * 32 + cout, 32 channels each
+        {
+            const int lr = lane >> 2, lp = lane & 3;
+            for (int piece = wave; piece < NP_W; piece += 4) {
+                const int R = piece * 16 + lr;
+                const int tap = R >> 5, co = R & 31;
+                glds16(w2 + co * (9 * C) + tap * C + c0 + ((lp ^ swz(R)) << 3), wl + piece * 1024);
+            }
+        }
+        // ---- patch of this pass
         if constexpr (SRC_UP == 0) {
-            const int lq = lane >> 3, lpos = lane & 7;
-            for (int piece = wave; piece < NPIECE; piece += 4) {
-                const int q = piece * 8 + lq;                // patch pixel
+            const int lr = lane >> 2, lp = lane & 3;
+            for (int piece = wave; piece < NP_PATCH; piece += 4) {
+                const int q = piece * 16 + lr;
                 const int py = q / PW, pxx = q - py * PW;
                 const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
                 const bool ok = q < NPIX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const int schk = (lpos ^ p_swz(q)) * 8;
-                const h16* src = ok ? in + (((size_t)b * H + iy) * W + ix) * C + c0 + schk : zero_page + schk;
+                const int sc = (lp ^ swz(q)) << 3;
+                const h16* src = ok ? in + ((b * H + iy) * W + ix) * C + c0 + sc : zero_page + sc;
                 glds16(src, patch + piece * 1024);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            // bilinear (align_corners=True) from the low-res tensor, 8 channels per item
-            for (int it = tid; it < NPIX * 8; it += 256) {
-                const int q = it >> 3, ch = it & 7;
-                const int py = q / PW, pxx = q - py * PW;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-                h16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                    const float sy = ys * (float)iy, sx = xs * (float)ix;
-                    const int ya = min((int)sy, h - 1), yb = min(ya + 1, h - 1);
-                    const int xa = min((int)sx, w - 1), xb = min(xa + 1, w - 1);
-                    const float wy = sy - (float)ya, wx = sx - (float)xa;
-                    const h16* base = in + (size_t)b * h * w * C + c0 + ch * 8;
-                    const h16x8 a00 = *reinterpret_cast<const h16x8*>(base + ((size_t)ya * w + xa) * C);
-                    const h16x8 a01 = *reinterpret_cast<const h16x8*>(base + ((size_t)ya * w + xb) * C);
-                    const h16x8 a10 = *reinterpret_cast<const h16x8*>(base + ((size_t)yb * w + xa) * C);
-                    const h16x8 a11 = *reinterpret_cast<const h16x8*>(base + ((size_t)yb * w + xb) * C);
+            // three batches of 2 patch pixels: all 8 gathers of a batch are issued before its first lerp (loads are
+            // unconditional - pixels outside the image read the tensor's first bytes and are zeroed afterwards)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float top = (float)a00[e] * (1.f - wx) + (float)a01[e] * wx;
-                        const float bot = (float)a10[e] * (1.f - wx) + (float)a11[e] * wx;
-                        o[e] = (h16)(top * (1.f - wy) + bot * wy);      // same rounding point as the standalone resize (fp16 tensor)
-                    }
+            for (int k0 = 0; k0 < NK; k0 += 2) {
+                h16x8 a00[2], a01[2], a10[2], a11[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = k0 + j;
+                    const unsigned o00 = (unsigned)(max(off00[k], 0) + c0);       // uniform base + 32-bit lane offset
+                    a00[j] = *reinterpret_cast<const h16x8*>(in + (size_t)o00);
+                    a01[j] = *reinterpret_cast<const h16x8*>(in + (size_t)(o00 + (unsigned)dxo[k]));
+                    a10[j] = *reinterpret_cast<const h16x8*>(in + (size_t)(o00 + (unsigned)dyo[k]));
+                    a11[j] = *reinterpret_cast<const h16x8*>(in + (size_t)(o00 + (unsigned)(dyo[k] + dxo[k])));
                 }
-                *reinterpret_cast<h16x8*>(patch + q * 128 + ((ch ^ p_swz(q)) << 4)) = o;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = k0 + j;
+                    const int q = (tid >> 2) + 64 * k;
+                    const h16x8 top = lerp8(a00[j], a01[j], wxh[k]);
+                    const h16x8 bot = lerp8(a10[j], a11[j], wxh[k]);
+                    h16x8 o = lerp8(top, bot, wyh[k]);
+                    if (off00[k] < 0) o = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (q < NPIX) *reinterpret_cast<h16x8*>(patch + q * ROWB + ((ch ^ swz(q)) << 4)) = o;
+                }
+                asm volatile("" ::: "memory");                                   // keep the next batch's gathers behind this batch's lerps (VGPR budget)
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // LDS-DMA landed before the barrier publishes it
         __syncthreads();
 
-        // ---- 9 taps x 4 k-steps: D[cout][pixel] += W2[cout][tap, c0 + 16ks ..] . patch[pixel + tap][..]
+        // ---- 3 kx x 2 k-steps: D[cout][pixel] += W2[cout][(ky,kx), c0 + 16ks ..] . patch[row + ky][pixel + kx][..]
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const h16* wrow = w2 + (size_t)px * (9 * C) + tap * C + c0 + hh * 8;      // A operand: row = cout (lane & 31)
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h16x8 wf = *reinterpret_cast<const h16x8*>(wrow + ks * 16);
+            for (int ks = 0; ks < 2; ++ks) {
+                h16x8 P[4], Wf[3];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int q = (wave * 2 + r + ky) * PW + px + kx;                  // patch pixel of this lane's output pixel
-                    const h16x8 pf = *reinterpret_cast<const h16x8*>(patch + q * 128 + (((2 * ks + hh) ^ p_swz(q)) << 4));
-                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, pf, acc[r], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (wave * 2 + j) * PW + px + kx;
+                    P[j] = *reinterpret_cast<const h16x8*>(patch + q * ROWB + (((2 * ks + hh) ^ swz(q)) << 4));
                 }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int R = (ky * 3 + kx) * 32 + px;                  // A operand: row = cout (lane & 31)
+                    Wf[ky] = *reinterpret_cast<const h16x8*>(wl + R * ROWB + (((2 * ks + hh) ^ swz(R)) << 4));
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[ky], P[r + ky], acc[r], 0, 0, 0);
             }
         }
     }
@@ -127,16 +200,20 @@ __global__ void __launch_bounds__(256) depth_tail_kernel(const h16* __restrict__
 extern "C" int vda_depth_tail_f16(const void* in, const void* w2, const float* b2, const float* w3, float b3, float* out,
                                   const void* zero_page, int B, int h, int w, int H, int W, int C, vda_stream_t stream) {
     VDA_REQUIRE(in && w2 && b2 && w3 && out && zero_page, "vda_depth_tail: null pointer");
-    VDA_REQUIRE(B > 0 && B <= 65535 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % CC == 0, "vda_depth_tail: bad geometry (C=%d must be a multiple of %d)", C, CC);
+    VDA_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % CC == 0, "vda_depth_tail: bad geometry (C=%d must be a multiple of %d)", C, CC);
     VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)w2 & 15) == 0, "vda_depth_tail: 16-byte alignment required");
-    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, B);
+    VDA_REQUIRE((double)B * h * w * C < 2147483647.0 && (double)B * H * W < 2147483647.0, "vda_depth_tail: tensor exceeds 32-bit element offsets");
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long long ntiles = (long long)tiles_x * tiles_y * B;
+    VDA_REQUIRE(ntiles < (1ll << 30), "vda_depth_tail: too many tiles");
+    const dim3 grid((unsigned)((ntiles + 7) / 8 * 8));
     hipStream_t s = (hipStream_t)stream;
     if (h == H && w == W)
         hipLaunchKernelGGL((depth_tail_kernel<0>), grid, dim3(256), 0, s, (const h16*)in, (const h16*)w2, b2, w3, b3, out, (const h16*)zero_page, h, w,
-                           H, W, C);
+                           H, W, C, tiles_x, tiles_y, (int)ntiles);
     else
         hipLaunchKernelGGL((depth_tail_kernel<1>), grid, dim3(256), 0, s, (const h16*)in, (const h16*)w2, b2, w3, b3, out, (const h16*)zero_page, h, w,
-                           H, W, C);
+                           H, W, C, tiles_x, tiles_y, (int)ntiles);
     VDA_LAUNCH_CHECK();
     return 0;
 }
