@@ -82,7 +82,7 @@ def main():
         model(x)
     outs = torch.empty(args.steps, T, H, W, dtype=torch.float32, device=dev)
     gathered = torch.empty(world * args.steps, T, H, W, dtype=torch.float32, device=dev) if world > 1 else None
-    ops.PROFILE = []
+    ops.PROFILE = ops.GemmProfile(every=4)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -103,14 +103,17 @@ def main():
 
     if rank == 0:
         # ---- dominant kernel: per-launch durations from the events recorded in the timed region
+        # (1 launch in 4 of each shape is bracketed; totals = sampled rate x all launches' algorithmic flops)
         agg = {}
-        for name, flops, e0, e1 in prof:
+        for name, flops, e0, e1 in prof.samples:
             a = agg.setdefault(name, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += flops
-        dom = max(agg, key=lambda k: agg[k][1])
-        calls, secs, flops = agg[dom]
+        est = {k: prof.launches[k][1] / (v[2] / v[1]) for k, v in agg.items()}      # estimated seconds in the timed region
+        dom = max(est, key=est.get)
+        sampled, secs, flops = agg[dom]
+        calls = prof.launches[dom][0]
         # HBM bytes per launch of that kernel: cannot be read live (needs rocprofv3 --pmc passes); taken from the
         # committed PMC summary of the same command (tools/pmc_bench.sh -> profiles/), null when absent.
         traffic = None
@@ -129,11 +132,12 @@ def main():
                        "clips_per_step_per_gpu": 1, "parallelism": f"independent windows x{world}" + (", one all-gather of depth" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": calls,
-                         "avg_launch_us": secs / calls * 1e6, "algorithmic_gflop_per_launch": flops / calls / 1e9,
-                         "share_of_step_time": secs / dt},
+                         "launches_timed": sampled, "avg_launch_us": secs / sampled * 1e6,
+                         "algorithmic_gflop_per_launch": flops / sampled / 1e9, "share_of_step_time": est[dom] / dt},
             "model_tflops": CLIP_TFLOP[args.encoder] * world * args.steps / dt,
             "model_mfma_frac": CLIP_TFLOP[args.encoder] * world * args.steps / dt / (MFMA_PEAK_TFLOPS * world),
-            "kernels": {k: {"launches": v[0], "ms_per_step": v[1] / args.steps * 1e3, "tflops": v[2] / v[1] / 1e12} for k, v in agg.items()},
+            "kernels": {k: {"launches": prof.launches[k][0], "launches_timed": v[0], "ms_per_step": est[k] / args.steps * 1e3,
+                            "tflops": v[2] / v[1] / 1e12} for k, v in agg.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.encoder)
