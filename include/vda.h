@@ -134,7 +134,7 @@ int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out,
 
 /* Fused depth tail (dpt.py:118-122, dpt_temporal.py:93-100, video_depth.py:162-163): NHWC fp16 [B,h,w,C] ->
  * [bilinear align_corners resize to H x W when (h,w) != (H,W)] -> 3x3 conv C->32 (+b2, ReLU) -> 1x1 conv 32->1 (+b3, ReLU)
- * -> fp32 [B,H,W]. w2: fp16 [32, 9*C] with K ordered (ky,kx,ci); C a multiple of 64; zero_page: >= 256 B of zeros. */
+ * -> fp32 [B,H,W]. w2: fp16 [32, 9*C] with K ordered (ky,kx,ci); C a multiple of 32; zero_page: >= 256 B of zeros. */
 int vda_depth_tail_f16(const void* in, const void* w2, const float* b2, const float* w3, float b3, float* out,
                        const void* zero_page, int B, int h, int w, int H, int W, int C, vda_stream_t stream);
 
@@ -145,6 +145,19 @@ int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W,
  * the window gather + key-frame refill of video_depth.py:197-201 without a host round trip. */
 int vda_gather_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H, int W,
                                 vda_stream_t stream);
+
+/* ---- window stitcher on the device (video_depth.py:216-254) ------------------------------------------------
+ * Least-squares scale / shift of `pred` against `target` over all n pixels (utils/util.py:40-62 with the all-ones
+ * mask of video_depth.py:232): scale_shift[0..1] (device) = closed form on fp64 sums, (1, 0) when det == 0.
+ * workspace: >= 4*nblk doubles (device); deterministic (fixed reduction order, no atomics). */
+int vda_lsq_scale_shift_f32(const float* pred, const float* target, long long n, double* workspace, int nblk, float* scale_shift,
+                            vda_stream_t stream);
+/* One window k > 0, frames of px pixels, win = fp32 [32, px] (video_depth.py:235-250, utils/util.py:65-74), aff(d) = max(d*scale+shift, 0):
+ *   chunk[0..7]  = tail[j]*wts[j] + aff(win[2+j])*wts[8+j]   (cross-fade, wts = (1-w_j | w_j), w = 0,1/7,..,1)
+ *   chunk[8..21] = aff(win[10..23]);  tail[0..7] = aff(win[24..31]);  ref1 = aff(win[12]).
+ * chunk: fp32 [22, px]; tail: fp32 [8, px] updated in place; scale_shift, wts: device fp32 [2], [16]. */
+int vda_stitch_window_f32(const float* win, const float* scale_shift, float* chunk, float* tail, float* ref1, long long px,
+                          const float* wts, vda_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,8 @@ def test_header_declares_the_hot_path():
 
 
 def test_library_exports_every_declared_symbol(libpath):
+    import torch  # noqa: F401  (its bundled libamdhip64.so must be the process's one HIP runtime, see _lib._load)
+    ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"), mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(libpath)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libvda_hip.so lacks {missing}"

@@ -346,3 +346,52 @@ def test_refusals(ops):
         ops.gemm(A, W, out, _lib.EPI_BIAS_F16, M=8, N=8, K=96)
     with pytest.raises(_lib.VdaError):
         ops.temporal_attention(torch.zeros(40 * 3 * 64, dtype=F16, device="cuda"), torch.zeros(40 * 64, dtype=F16, device="cuda"), 40, 1, 64)
+
+
+# ---------------------------------------------------------------------------
+# device stitcher (video_depth.py:216-254, utils/util.py:40-74) vs the numpy restatement in scheduler.py
+# ---------------------------------------------------------------------------
+def test_lsq_scale_shift_matches_closed_form():
+    from video_depth_anything_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pred = torch.rand(2, 61, 47, device="cuda", generator=g) * 3 + 0.5
+    target = pred * 1.7 - 0.4 + 0.05 * torch.randn(2, 61, 47, device="cuda", generator=g)
+    ws = torch.empty(4 * ops.LSQ_BLOCKS, dtype=torch.float64, device="cuda")
+    ss = torch.zeros(2, dtype=torch.float32, device="cuda")
+    ops.lsq_scale_shift(pred, target, ws, ss)
+    p, t = pred.double().cpu().numpy().ravel(), target.double().cpu().numpy().ravel()
+    A = np.stack([p, np.ones_like(p)], 1)
+    sol = np.linalg.lstsq(A, t, rcond=None)[0]
+    np.testing.assert_allclose(ss.cpu().numpy(), sol, rtol=1e-6)
+    ss2 = torch.zeros(2, dtype=torch.float32, device="cuda")
+    ops.lsq_scale_shift(pred, target, ws, ss2)
+    assert torch.equal(ss, ss2), "reduction must be deterministic"
+    # degenerate system (constant prediction): det == 0 -> identity, as utils/util.py:56-62
+    c = torch.full((2, 8, 8), 2.0, device="cuda")
+    ops.lsq_scale_shift(c, c * 3, ws, ss)
+    assert ss.cpu().tolist() == [1.0, 0.0]
+
+
+@pytest.mark.parametrize("n_frames,metric", [(50, False), (50, True), (32, False), (97, False), (23, True)])
+def test_device_stitcher_matches_host_stitcher(n_frames, metric):
+    from video_depth_anything_amd import scheduler as S
+    from video_depth_anything_amd.stitch import stitch_stream
+    H0, W0 = 37, 45
+    plan = S.plan_windows(n_frames)
+    rng = np.random.default_rng(n_frames)
+    base = rng.random((H0, W0), dtype=np.float32) * 4 + 1
+    wins = []
+    for k in range(len(plan)):
+        # every window sees the same scene at its own scale/shift plus noise, like real window outputs
+        w = base[None] * (1 + 0.1 * rng.standard_normal((32, 1, 1))).astype(np.float32)
+        w = (w * (0.6 + 0.3 * k) + 0.2 * k + 0.02 * rng.standard_normal((32, H0, W0))).astype(np.float32)
+        wins.append(np.maximum(w, 0))
+    ref = S.stitch_windows(wins, n_frames, metric=metric)
+    dev = torch.device("cuda")
+    got = stitch_stream((torch.from_numpy(w).to(dev) for w in wins), n_frames, H0, W0, dev, metric=metric)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    if metric:
+        assert np.array_equal(got, ref), "metric stitch has no fitted parameters: bit-exact"
+    else:
+        # scale/shift: fp64 sums on the device vs numpy's fp32 sums in the closed form (its det cancels digits)
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)

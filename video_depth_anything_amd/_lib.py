@@ -45,6 +45,8 @@ SIGNATURES = {
     "vda_depth_tail_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_normalize_u8_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_gather_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_lsq_scale_shift_f32": (_i, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
+    "vda_stitch_window_f32": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp]),
 }
 
 

@@ -15,6 +15,9 @@ LIB = os.path.join(HERE, "libvda_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr copies around the softmax / epilogues
+# Per-file overrides (appended, so they win). stitch.hip restates numpy float32 array arithmetic (a*b + c with two
+# roundings): -ffp-contract=fast fuses in the backend regardless of source pragmas, so that file is built without it.
+PER_FILE = {"stitch.hip": ["-ffp-contract=off"]}
 
 
 def _sources():
@@ -32,7 +35,7 @@ def _compile(src):
     sp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
         return obj
-    cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+    cmd = [HIPCC] + FLAGS + PER_FILE.get(src, []) + ["-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -187,6 +187,27 @@ def gather_normalize_u8(video, idx, out, n, H, W):
     check(lib.vda_gather_normalize_u8_f32(_p(video), _p(idx), _p(out), n, video.shape[0], H, W, _stream()), "vda_gather_normalize_u8_f32")
 
 
+LSQ_BLOCKS = 256
+
+
+def lsq_scale_shift(pred, target, workspace, scale_shift):
+    """scale_shift[0..1] (device fp32) = least-squares fit target ~ scale*pred + shift over all elements."""
+    _req(pred, F32, "pred"), _req(target, F32, "target"), _req(workspace, torch.float64, "workspace"), _req(scale_shift, F32, "scale_shift")
+    if pred.numel() != target.numel() or workspace.numel() < 4 * LSQ_BLOCKS or scale_shift.numel() < 2:
+        raise ValueError("lsq_scale_shift: mismatched sizes")
+    check(lib.vda_lsq_scale_shift_f32(_p(pred), _p(target), pred.numel(), _p(workspace), LSQ_BLOCKS, _p(scale_shift), _stream()),
+          "vda_lsq_scale_shift_f32")
+
+
+def stitch_window(win, scale_shift, chunk, tail, ref1, px, wts):
+    """Affine + clamp + cross-fade + append of one window (k > 0); see include/vda.h."""
+    for t, nm in ((win, "win"), (scale_shift, "scale_shift"), (chunk, "chunk"), (tail, "tail"), (ref1, "ref1"), (wts, "wts")):
+        _req(t, F32, nm)
+    if win.numel() < 32 * px or chunk.numel() < 22 * px or tail.numel() < 8 * px or ref1.numel() < px or wts.numel() < 16:
+        raise ValueError("stitch_window buffers too small")
+    check(lib.vda_stitch_window_f32(_p(win), _p(scale_shift), _p(chunk), _p(tail), _p(ref1), px, _p(wts), _stream()), "vda_stitch_window_f32")
+
+
 # ---------------------------------------------------------------------------
 # Weight layouts the kernels expect (done once at load time, on the host or device)
 # ---------------------------------------------------------------------------

@@ -63,6 +63,14 @@ def shard_windows(n_windows: int, world: int, rank: int) -> range:
     return range(lo, lo + q + (1 if rank < r else 0))
 
 
+def gathered_order(n_windows: int, world: int) -> Tuple[int, List[int]]:
+    """Layout of the all-gather: every rank sends `per` window slots (short ranks pad); returns (per, flat slot index
+    r * per + j of window 0, 1, 2, ... in window order)."""
+    per = (n_windows + world - 1) // world
+    order = [r * per + j for r in range(world) for j in range(len(shard_windows(n_windows, world, r)))]
+    return per, order
+
+
 # ------------------------------------------------------------------ stitching
 def compute_scale_and_shift(prediction: np.ndarray, target: np.ndarray) -> Tuple[float, float]:
     """Closed-form least squares target ~ scale*prediction + shift over all pixels
@@ -147,7 +155,7 @@ def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray
         return stitch_windows(local, n, metric)
 
     H0, W0 = frames.shape[1:3]
-    per = (len(plan) + world - 1) // world                      # pad short ranks to a common count
+    per, order = gathered_order(len(plan), world)               # short ranks pad to a common count
     use_cuda = dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
     send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
@@ -155,12 +163,8 @@ def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray
         send[:len(local)] = torch.from_numpy(np.stack(local)).to(dev)
     recv = torch.empty(world * per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.cpu().numpy().reshape(world, per, INFER_LEN, H0, W0)
-    ordered = []
-    for r in range(world):
-        for j, _ in enumerate(shard_windows(len(plan), world, r)):
-            ordered.append(recv[r, j])
-    return stitch_windows(ordered, n, metric)
+    recv = recv.cpu().numpy()
+    return stitch_windows([recv[i] for i in order], n, metric)
 
 
 def normalize_frames_host(frames_u8: np.ndarray) -> np.ndarray:

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .config import INFER_LEN, get_config
-from .scheduler import network_size, run_windows
+from .scheduler import network_size
 
 _FP32_WARNED = False
 
@@ -87,45 +87,46 @@ class VideoDepthAnything:
         H0, W0 = frames.shape[1:3]
         H, W = network_size(H0, W0, input_size)
 
+        import torch.distributed as dist
+        from .scheduler import gathered_order, plan_windows, shard_windows
+        from .stitch import stitch_stream
         dev = eng.device
+        n = frames.shape[0]
+        plan = plan_windows(n)
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
         video = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)          # the whole uint8 video, uploaded ONCE
-        compute = torch.cuda.current_stream(dev)
-        copy_stream = torch.cuda.Stream(device=dev)
-        pinned = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, pin_memory=True) for _ in range(2)]
-        dbuf = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)]
-        done = [torch.cuda.Event() for _ in range(2)]
         xin = torch.empty(1, INFER_LEN, 3, H0, W0, dtype=torch.float32, device=dev)
 
-        def batch_fn(index_lists):
-            """Windows of this rank, software-pipelined: window j's single D2H (pinned, side stream) overlaps window
-            j+1's gather/normalise/forward/resize on the compute stream."""
-            outs = []
-            for j, idxs in enumerate(index_lists):
-                s = j & 1
-                idx = torch.tensor(idxs, dtype=torch.int32, device=dev)
-                ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)      # video_depth.py:197-201 on the device
-                x = xin
-                if (H0, W0) != (H, W):
-                    # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is absent offline,
-                    # so this leg is PARITY UNPINNED: device bicubic (a=-0.75, half-pixel centres); normalisation is affine,
-                    # so resizing after it is equivalent.
-                    x = torch.nn.functional.interpolate(xin[0], size=(H, W), mode='bicubic', align_corners=False)[None]
-                depth = eng.forward(x)                                           # [1,32,H,W] fp32
-                ops.bilinear_plane(depth.view(INFER_LEN, H, W), dbuf[s], INFER_LEN, H, W, H0, W0)   # video_depth.py:207-208
-                copy_stream.wait_stream(compute)
-                with torch.cuda.stream(copy_stream):
-                    pinned[s].copy_(dbuf[s], non_blocking=True)                  # the window's ONE D2H
-                    done[s].record(copy_stream)
-                if j > 0:
-                    done[s ^ 1].synchronize()
-                    outs.append(pinned[s ^ 1].numpy().copy())
-            if index_lists:
-                last = (len(index_lists) - 1) & 1
-                done[last].synchronize()
-                outs.append(pinned[last].numpy().copy())
-            return outs
+        def window_depth(idxs, out):
+            """One window on the device: gather + normalise (video_depth.py:197-201), forward, resize to the source
+            size (video_depth.py:207-208) into out [32,H0,W0]."""
+            idx = torch.tensor(idxs, dtype=torch.int32, device=dev)
+            ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)
+            x = xin
+            if (H0, W0) != (H, W):
+                # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is absent offline,
+                # so this leg is PARITY UNPINNED: device bicubic (a=-0.75, half-pixel centres); normalisation is affine,
+                # so resizing after it is equivalent.
+                x = torch.nn.functional.interpolate(xin[0], size=(H, W), mode='bicubic', align_corners=False)[None]
+            depth = eng.forward(x)                                               # [1,32,H,W] fp32
+            ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)
+            return out
 
-        depths = run_windows(frames, metric=self.METRIC, batch_fn=batch_fn)
+        if world == 1:
+            wbuf = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            windows = (window_depth(idxs, wbuf) for idxs in plan)                # lazily: stitch k queues behind forward k
+        else:
+            # One process per GPU: this rank computes its block of windows with no data-path collective, ONE all-gather
+            # (RCCL over xGMI) hands every rank all depth maps, and each rank stitches the whole sequence on its own GPU.
+            per, order = gathered_order(len(plan), world)
+            send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            for j, k in enumerate(shard_windows(len(plan), world, rank)):
+                window_depth(plan[k], send[j])
+            recv = torch.empty(world * per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(recv, send)
+            windows = (recv[i] for i in order)
+        depths = stitch_stream(windows, n, H0, W0, dev, metric=self.METRIC)
         return depths, target_fps
 
 
