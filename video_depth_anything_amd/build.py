@@ -17,7 +17,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form"]   # MFMA results in VGPRs: no v_accvgpr copies around the softmax / epilogues
 # Per-file overrides (appended, so they win). stitch.hip restates numpy float32 array arithmetic (a*b + c with two
 # roundings): -ffp-contract=fast fuses in the backend regardless of source pragmas, so that file is built without it.
+# The GEMM epilogues are scalar fp32 code per output element: the SLP vectoriser pairs neighbouring adds into
+# v_pk_add_f32 (several times the issue cost of two v_add_f32 on gfx950) with the pairs misaligned against the
+# fp16 packing, which costs more shuffles than arithmetic - off for those files.
 PER_FILE = {"stitch.hip": ["-ffp-contract=off"]}
+PER_PREFIX = {"gemm": ["-fno-slp-vectorize"]}
 
 
 def _sources():
@@ -35,7 +39,11 @@ def _compile(src):
     sp = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(sp), _deps_mtime()):
         return obj
-    cmd = [HIPCC] + FLAGS + PER_FILE.get(src, []) + ["-c", sp, "-o", obj]
+    extra = list(PER_FILE.get(src, []))
+    for prefix, fl in PER_PREFIX.items():
+        if src.startswith(prefix):
+            extra += fl
+    cmd = [HIPCC] + FLAGS + extra + ["-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

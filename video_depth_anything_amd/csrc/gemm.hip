@@ -203,6 +203,10 @@ int vda_gemm256s_dense_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 
+// gemm8p_*.hip: 256 x 256 tile, 8-phase two-group schedule
+int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm8p_conv_bn256(const vda_gemm_args& a, hipStream_t s);
+
 static int vda_gemm256s_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
     if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256s_dense_bn256(a, s) : vda_gemm256s_dense_bn128(a, s);
     return bn == 256 ? vda_gemm256s_conv_bn256(a, s) : vda_gemm256s_conv_bn128(a, s);
@@ -275,8 +279,11 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         if (a.a_mode == VDA_A_DENSE) return narrow0 ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
         return narrow0 ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
     }
-    // variants: -1 auto; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 on 32x32x16 MFMA; 3 / 4 = the same on 16x16x32 MFMA
+    // variants: -1 auto; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 on 32x32x16 MFMA; 3 / 4 = the same on 16x16x32 MFMA;
+    // 5 = 256x256 8-phase two-group schedule (16x16x32 MFMA)
     int big = 0, small_mfma = 1;
+    bool eight = g_gemm_variant >= 5 && (g_gemm_variant & 15) == 5;      // upper bits: A/B switches of the 8-phase kernel
+    if (eight) big = 256;
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
     if (g_gemm_variant == 2 || g_gemm_variant == 4) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
@@ -284,19 +291,24 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // large-tile kernel; BN picked for the smaller padded width
         const int pad256 = (a.N + 255) / 256 * 256, pad128 = (a.N + 127) / 128 * 128;
         big = pad128 < pad256 ? 128 : 256;
-        // measured (tools/gemm_bench.py): the 16x16x32 shape wins everywhere except the short-K in-place fp32 residual GEMM
-        if (a.epilogue == VDA_EPI_SCALE_RES_F32 && a.K <= 2048) small_mfma = 0;
+        // 256 x 256 dense: the 8-phase two-group schedule (tools/gemm_ab.py, in-process A/B: -4..-15 % on every encoder shape and
+        // epilogue); conv A keeps the one-barrier kernel (within +-2 %)
+        if (big == 256 && a.a_mode == VDA_A_DENSE) eight = true;
     }
     if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
         VDA_REQUIRE(g_gemm_variant < 0, "vda_gemm_f16: the 256-row kernel needs N and ldc to be multiples of 8");
         big = 0;                            // its epilogue owns 8-column (16-byte) row segments
     }
     if (big) {
-        const int rc = small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s);
+        vda_gemm_args a8 = a;
+        if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
+        const int rc = eight ? (a.a_mode == VDA_A_DENSE ? vda_gemm8p_dense_bn256(a8, s) : vda_gemm8p_conv_bn256(a8, s))
+                             : small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s);
         if (rc >= 0) {
-            // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue>
+            // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>
             static thread_local char name[64];
-            snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
+            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d>", big, a.a_mode, a.epilogue);
+            else snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
             g_last_kernel = name;
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel

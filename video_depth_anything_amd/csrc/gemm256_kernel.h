@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(NT) gemm256_kernel(const vda_gemm_args p) {
         // (16-byte chunks XOR-swizzled by row: conflict-free both ways) and then owns whole row segments: bias / LayerScale /
         // residual reads and the output stores become contiguous 16-byte accesses covering full 128-byte lines.
         const int bm0 = m0 + wm * WTM, bn0 = n0 + wn * WTN;
+        const bool interior = bm0 + WTM <= p.M && bn0 + WTN <= p.N;       // wave-uniform
         {
             using RT = vda_gemm::RowTraits<EPI>;
             constexpr int NC = RT::NC, RR = RT::f32_out ? 8 : 4;            // columns per lane, row groups per 32-row block
@@ -213,6 +214,8 @@ __global__ void __launch_bounds__(NT) gemm256_kernel(const vda_gemm_args p) {
             const bool geglu_idle = (EPI == VDA_EPI_GEGLU_F16) && (c0 & 7) >= 4;   // gate lanes only feed their value lanes
             vda_gemm::ColConst<NC> cc;
             vda_gemm::load_col_const<EPI, NC>(p, en, cc);
+            constexpr int RG = RT::f32_out ? 4 : 2;                          // rows per row group
+            vda_gemm::RowAux carry[RG];                                      // the next block's first group, loaded a group early
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -228,39 +231,57 @@ __global__ void __launch_bounds__(NT) gemm256_kernel(const vda_gemm_args p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 // Row groups are processed RG at a time: phase 1 issues every row-dependent global load of the group,
                 // phase 2 reads the transposed accumulators back, finishes and stores.
-                constexpr int RG = RT::f32_out ? 4 : 2;
+                // Row-dependent loads (residuals, pos-embed) run ONE ROW GROUP AHEAD of the stores: vmcnt retires in order and
+                // counts stores, so a load issued after a group's stores cannot complete before them - issued before, it can.
+                auto row_groups = [&](auto guard) {
+                    constexpr bool GUARD = decltype(guard)::value;
+                    constexpr int NG = RR / RG;                                  // row groups per 32-row block
+                    auto load_group = [&](int blk, int r0, vda_gemm::RowAux (&ax)[RG]) {
+                        if (!geglu_idle) {
 #pragma unroll
-                for (int r0 = 0; r0 < RR; r0 += RG) {
-                    vda_gemm::RowAux aux[RG];
-                    if (!geglu_idle) {
+                            for (int q = 0; q < RG; ++q)
+                                vda_gemm::load_row_aux<EPI, GUARD>(p, bm0 + blk * 32 + (r0 + q) * (32 / RR) + lrow_e, en, ax[q]);
+                        }
+                    };
+                    vda_gemm::RowAux aux[2][RG];
+                    if (i == 0) load_group(0, 0, aux[0]);
+                    else {
 #pragma unroll
-                        for (int q = 0; q < RG; ++q)
-                            vda_gemm::load_row_aux<EPI>(p, bm0 + i * 32 + (r0 + q) * (32 / RR) + lrow_e, en, aux[q]);
+                        for (int q = 0; q < RG; ++q) aux[0][q] = carry[q];
                     }
 #pragma unroll
-                    for (int q = 0; q < RG; ++q) {
-                        const int row = (r0 + q) * (32 / RR) + lrow_e;
-                        const char* rp = stg + row * 256;
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(rp + ((c0 ^ (row & 15)) << 4));
-                        if constexpr (RT::f32_out) {
-                            vda_gemm::finish_row4<EPI>(p, bm0 + i * 32 + row, en, a, cc, aux[q]);
-                        } else {
-                            const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((c0 + 1) ^ (row & 15)) << 4));
-                            float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-                            float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                            if constexpr (EPI == VDA_EPI_GEGLU_F16) {
-                                const f32x4 ga = *reinterpret_cast<const f32x4*>(rp + (((c0 + 4) & 15) ^ (row & 15)) * 16);
-                                const f32x4 gb = *reinterpret_cast<const f32x4*>(rp + (((c0 + 5) & 15) ^ (row & 15)) * 16);
+                    for (int g = 0; g < NG; ++g) {
+                        const int r0 = g * RG;
+                        if (g + 1 < NG) load_group(i, r0 + RG, aux[(g + 1) & 1]);
+                        else if (i + 1 < MI) load_group(i + 1, 0, carry);        // first group of the next block
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    gt[e] = ga[e];
-                                    gt[4 + e] = gb[e];
+                        for (int q = 0; q < RG; ++q) {
+                            const int row = (r0 + q) * (32 / RR) + lrow_e;
+                            const char* rp = stg + row * 256;
+                            const f32x4 a = *reinterpret_cast<const f32x4*>(rp + ((c0 ^ (row & 15)) << 4));
+                            if constexpr (RT::f32_out) {
+                                vda_gemm::finish_row4<EPI, GUARD>(p, bm0 + i * 32 + row, en, a, cc, aux[g & 1][q]);
+                            } else {
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((c0 + 1) ^ (row & 15)) << 4));
+                                float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                                float gt[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                                if constexpr (EPI == VDA_EPI_GEGLU_F16) {
+                                    const f32x4 ga = *reinterpret_cast<const f32x4*>(rp + (((c0 + 4) & 15) ^ (row & 15)) * 16);
+                                    const f32x4 gb = *reinterpret_cast<const f32x4*>(rp + (((c0 + 5) & 15) ^ (row & 15)) * 16);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        gt[e] = ga[e];
+                                        gt[4 + e] = gb[e];
+                                    }
                                 }
+                                if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
                             }
-                            if (!geglu_idle) vda_gemm::finish_row8<EPI>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[q]);
                         }
                     }
-                }
+                };
+                // interior wave tiles (all but the matrix's last row / column of tiles) take the branch-free form
+                if (interior) row_groups(std::false_type{});
+                else row_groups(std::true_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
             }
         }

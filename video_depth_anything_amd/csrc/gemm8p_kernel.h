@@ -1,27 +1,29 @@
-// Large-tile fp16 MFMA GEMM / implicit-GEMM conv for gfx950: 256 x BN x 64 tiles, 8 waves, one
-// workgroup per CU. This is the kernel the encoder's qkv/proj/fc1/fc2 GEMMs and the head's wide convs run on.
+// 8-phase, two-group (ping-pong) schedule of the 256 x 256 x 64 fp16 MFMA GEMM / implicit-GEMM conv for gfx950.
+// Same tile, LDS image (rows of 128 B, 16-byte chunks XOR-swizzled by (row >> 1) & 7 on the DMA SOURCE address and on the
+// read), fragment shapes (v_mfma_f32_16x16x32_f16, swapped operands), persistence and epilogue as gemm8p_kernel.h;
+// what changes is WHEN things are issued:
 //
-// Why this shape: with a 128x128 tile every 32 MFMAs per wave need 32 KB staged from L2 into LDS; at MFMA
-// peak that is more than the L2 can deliver, so the small tile is staging-bound. 256x256 halves the staged
-// bytes per FLOP (64 KB per 64 MFMAs per wave) and the 128x64 wave tile cuts LDS fragment reads to
-// 0.75 ds_read_b128 per v_mfma_f32_32x32x16_f16.
+//   * A K tile is four phases of 16 MFMAs: (k-step 0, rows lo), (k0, rows hi), (k1, rows lo), (k1, rows hi) of the wave's
+//     128 x 64 tile. A phase = { ds_read its fragments (8 / 4 / 8 / 4 x b128) ; issue a slice of the LDS-DMA of K tile
+//     kt+2 ; lgkmcnt(0) ; s_barrier ; 16 MFMAs at s_setprio 1 ; s_barrier }.
+//   * Waves 4..7 (the SIMD partners of waves 0..3) run ONE BARRIER BEHIND waves 0..3: while one wave of a SIMD is in its
+//     MFMA section its partner is in its load section, so the DMA issue cost (60..185 cycles per 1-KiB piece, measured in
+//     MI355X_MICROARCH.md) and the LDS reads never hold the matrix pipe. In the one-barrier-per-K-tile kernel both waves of
+//     a SIMD issue their 8-piece DMA burst at the same moment (skipping the DMA there saves 24 %).
+//   * LDS-DMA stays in flight across barriers: raw s_barrier, counted s_waitcnt vmcnt(8) once per K tile (phase 4) instead
+//     of vmcnt(0) + __syncthreads. A is triple-buffered (3 x 32 KiB), W double-buffered (2 x 32 KiB) = 160 KiB: A(kt+2)
+//     is issued in phases 1-2 of K tile kt (2 + 2 pieces per wave), W(kt+2) in phase 4 (its slot is K tile kt's own,
+//     last read in phase 3), so every piece has at least a whole K tile of MFMA time to land.
 //
-// Pipeline (one __syncthreads per 64-deep K tile):
-//   LDS holds two K tiles (2 x 64 KB at BN=256). Fragments are register double-buffered at 16-deep k-step
-//   granularity: while the 8 MFMAs of step t issue, the 6 ds_read_b128 of step t+1 are in flight. The last
-//   step of tile k waits for tile k+1 (issued one whole tile earlier), barriers once, issues the 8
-//   global_load_lds of tile k+2 into the buffer tile k just vacated, and prefetches tile k+1's first
-//   fragments while its own MFMAs run, so the barrier never exposes an LDS or HBM round trip.
-//
-// LDS image: [rows][8 x 16 B], chunk ^= (row >> 1) & 7 (conflict-free for the 32-row ds_read_b128 fragment),
-// applied on the DMA SOURCE address and on the read address. MFMA operands are swapped (W rows as "A",
-// activation rows as "B") so a lane's accumulator registers are runs of 4 consecutive output columns.
-// 16x16x32-MFMA variant of gemm256_kernel.h (same tile, DMA, LDS image, persistence and epilogue; the K loop
-// is pipelined in units of 16 MFMAs: one 32-deep k step x half of the wave's rows).
+// Ordering rules followed (cdna_hip_programming.md, "The 256^2 8-phase template"):
+//   RAW: a wave's counted vmcnt precedes its phase-4 barrier; K tile kt+1 is first read in phase 1 of the next K tile, i.e.
+//        after a barrier every wave passed AFTER its own wait (group 1's phase-4 barrier 1 is group 0's barrier 2).
+//   WAR: every reading phase drains lgkmcnt(0) BEFORE its first barrier; a slot is re-staged no earlier than the phase
+//        after its last read (A: last read phase 4 of K tile kt-1, re-staged phase 1 of kt; W: phase 3 -> phase 4).
 #pragma once
 #include "gemm_epilogue.h"
 
-namespace vda_gemm256s {
+namespace vda_gemm8p {
 
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;
@@ -30,14 +32,16 @@ constexpr int NW = 8;                 // waves
 constexpr int NT = NW * 64;
 
 template <int BN, int AMODE, int EPI>
-__global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
+__global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
     constexpr int WM = NW / WN;                    // waves along M
     constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile: 128x64 (BN=256) or 64x64 (BN=128)
     constexpr int MI = WTM / 16, NJ = WTN / 16;    // 16x16 subtiles per wave
     constexpr int MH = MI / 2;                       // subtiles per half of the wave's rows (pipeline unit)
     constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;   // 1-KiB DMA pieces per wave
-    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + W_BYTES;
+    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
+    static_assert(BN == 256, "the 8-phase schedule is built for the 256 x 256 tile");
+    constexpr int A_SLOTS = 3, W_BASE = A_SLOTS * A_BYTES;          // [A0 | A1 | A2 | W0 | W1] = 160 KiB
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -83,36 +87,42 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
         }
     };
 
-    auto stage = [&](int kt, char* buf) {
+    // A pieces j = 2h, 2h+1 of a wave lie in rows [128h, 128h + 128): the half read by wave group h.
+    auto stage_a = [&](int kt, int j0, char* abuf) {
         const int k0 = kt * BK;
         if constexpr (AMODE == VDA_A_DENSE) {
 #pragma unroll
-            for (int j = 0; j < AJ; ++j) {
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j0 + jj;
                 const int m = min(tm0 + (wave + NW * j) * 8 + lrow, p.M - 1);
-                glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), buf + (wave + NW * j) * 1024);
+                glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), abuf + (wave + NW * j) * 1024);
             }
         } else {
             const int tap = k0 / p.cCin, ci0 = k0 - tap * p.cCin;
             const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-            for (int j = 0; j < AJ; ++j) {
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j0 + jj;
                 const int iy = (int)(short)(a_yx[j] & 0xffff) + ky, ix = (a_yx[j] >> 16) + kx;
                 const bool ok = (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
                 const h16* src = ok ? (const h16*)p.A + ((size_t)(a_pix[j] + iy * p.cW + ix) * p.cCin + ci0 + src_chk)
                                     : (const h16*)p.zero_page + src_chk;
-                glds16(src, buf + (wave + NW * j) * 1024);
+                glds16(src, abuf + (wave + NW * j) * 1024);
             }
         }
+    };
+    auto stage_w = [&](int kt, char* wbuf) {
+        const int k0 = kt * BK;
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
             const int n = min(tn0 + (wave + NW * j) * 8 + lrow, p.N - 1);
-            glds16((const h16*)p.W + (size_t)(unsigned)(n * p.K + src_chk + k0), buf + A_BYTES + (wave + NW * j) * 1024);
+            glds16((const h16*)p.W + (size_t)(unsigned)(n * p.K + src_chk + k0), wbuf + (wave + NW * j) * 1024);
         }
     };
 
     // fragment addressing: row = lane & 15 inside a 16-row subtile, k-chunk = 4*ks + (lane >> 4)
     const int frow = lane & 15, fh = lane >> 4, fsw = (lane >> 1) & 7;     // ((row >> 1) & 7) with row = subtile*16 + frow
-    const int a_off = (wm * WTM + frow) * ROW_BYTES, w_off = A_BYTES + (wn * WTN + frow) * ROW_BYTES;
+    const int a_off = (wm * WTM + frow) * ROW_BYTES, w_off = (wn * WTN + frow) * ROW_BYTES;
     // relu on the activation operand (conv only), branch-free: max(x, 0) or max(x, -inf)
     const h16 relu_floor = (p.relu_in & 1) ? (h16)0.f : (h16)(-65504.f);
     h16x8 relu_thr;
@@ -138,14 +148,27 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
 
     const int nt = p.K / BK;
     static_assert(WTN == 64, "epilogue staging assumes a 64-column wave tile");
-    // epilogue staging (8 waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
-    constexpr int STG_OFF = (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
-    char* stg = smem + STG_OFF + wave * 8192;
+    // epilogue staging (8 waves x 8 KiB) = A slots 1 and 2: free once the K loop's reads are done, while A slot 0 / W slot 0
+    // already receive the next tile's first K tile
+    char* stg = smem + A_BYTES + wave * 8192;
+
+    auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+    // raw barrier: no vmcnt(0) (LDS-DMA stays in flight across it); the empty asm statements keep LDS accesses on their
+    // side of it at IR level (the intrinsic itself is not a memory operation), sched_barrier pins the machine schedule
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+    };
 
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
     set_sources(tile);
-    stage(0, smem);
+    stage_a(0, 0, smem);
+    stage_a(0, 2, smem);
+    stage_w(0, smem + W_BASE);
     for (int round = 0; tile < ntiles; ++round) {
         const int bm = tile / nbn, bn = tile - bm * nbn;
         const int m0 = bm * BM, n0 = bn * BN;
@@ -160,6 +183,7 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
 #pragma unroll
                 for (int i = 0; i < MH; ++i) fa.a[i] = __builtin_elementwise_max(fa.a[i], relu_thr);
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MH; ++i)
 #pragma unroll
@@ -167,46 +191,78 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
                     if (half == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[i][j], 0, 0, 0);
                     else acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[MH + i][j], 0, 0, 0);
                 }
+            __builtin_amdgcn_s_setprio(0);
         };
 
-        // K tile 0 of this tile was issued before the previous tile's epilogue (or above, for the first tile).
-        AF a0, a1;
-        WF w0, w1;
+        // K tile 0 of this tile (A slot 0, W slot 0) was issued before the previous tile's epilogue (or above).
+        AF fa;
+        WF fw;
         if (round > 0) set_sources(tile);       // recomputed rather than kept live across the epilogue
-        // Full barrier (with its fences, so no LDS read can be scheduled above it): K tile 0 has landed everywhere.
-        // K tile 1 is issued after it and has the whole of K tile 0's MFMA work to land, as in the steady state.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (nt > 1) stage(1, smem + STAGE);
-        read_w(smem, 0, w0);
-        read_a(smem, 0, 0, a0);
-        for (int kt = 0; kt < nt; ++kt) {
-            char* cb = smem + (kt & 1) * STAGE;
-            char* nb = smem + ((kt + 1) & 1) * STAGE;
-            read_a(cb, 0, 1, a1);
-            read_w(cb, 1, w1);
-            mma(0, a0, w0);
-            read_a(cb, 1, 0, a0);
-            mma(1, a1, w0);
-            read_a(cb, 1, 1, a1);
-            mma(0, a0, w1);
-            // Tile kt+1 must have landed everywhere and every wave must be done READING tile kt (its last fragments
-            // are already in a1 / w1 once lgkmcnt drains): one full barrier per K tile, explicit DMA drain first.
+        if (nt > 1) {                           // K tile 1 -> A slot 1 (the epilogue staging area: released by the tile-end barrier)
+            stage_a(1, 0, smem + A_BYTES);
+            stage_a(1, 2, smem + A_BYTES);
+            stage_w(1, smem + W_BASE + W_BYTES);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // K tile 0 landed (mine); K tile 1 stays in flight
+        } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (kt + 2 < nt) stage(kt + 2, cb);
-            if (kt + 1 < nt) {
-                read_w(nb, 0, w0);
-                read_a(nb, 0, 0, a0);
-            }
-            mma(1, a1, w1);
         }
-        // After the loop's last barrier nobody reads the pipeline buffers any more: start the NEXT tile's first
-        // K tile now, so its HBM/L2 latency is covered by this tile's epilogue.
+        bar();                                  // ... and everyone's
+        if (wm == 1) bar();                     // waves 4..7 run one barrier behind from here to the end of the K loop
+
+        int sa = 0;                             // A slot of K tile kt (kt % 3)
+        for (int kt = 0; kt < nt; ++kt) {
+            const char* ab = smem + sa * A_BYTES;
+            const char* wb = smem + W_BASE + (kt & 1) * W_BYTES;
+            const int sa2 = sa == 0 ? 2 : sa - 1;                   // (kt + 2) % 3
+            char* ab2 = smem + sa2 * A_BYTES;
+            const bool more = kt + 2 < nt;
+            // phase 1: k-step 0, rows lo
+            read_w(wb, 0, fw);
+            read_a(ab, 0, 0, fa);
+            if (more) stage_a(kt + 2, 0, ab2);
+            lgkm0();
+            bar();
+            mma(0, fa, fw);
+            bar();
+            // phase 2: k-step 0, rows hi
+            read_a(ab, 0, 1, fa);
+            if (more) stage_a(kt + 2, 2, ab2);
+            lgkm0();
+            bar();
+            mma(1, fa, fw);
+            bar();
+            // phase 3: k-step 1, rows lo (last read of this K tile's W slot)
+            read_w(wb, 1, fw);
+            read_a(ab, 1, 0, fa);
+            lgkm0();
+            bar();
+            mma(0, fa, fw);
+            bar();
+            // phase 4: k-step 1, rows hi (last read of this K tile's A slot); W(kt+2) into the W slot just released
+            read_a(ab, 1, 1, fa);
+            if (more) {
+                stage_w(kt + 2, const_cast<char*>(wb));
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile kt+1 landed; A(kt+2), W(kt+2) stay in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lgkm0();
+            bar();
+            mma(1, fa, fw);
+            bar();
+            sa = sa == 2 ? 0 : sa + 1;
+        }
+        if (wm == 0) bar();                     // re-align the two groups: every wave is past its last MFMA section's reads
+        // Nobody reads the pipeline buffers any more. The NEXT tile's first K tile is issued after the first 32-row block of
+        // the epilogue (below): early enough that the rest of the epilogue covers its HBM/L2 latency, late enough that the
+        // epilogue's own first loads (column constants, residual rows) do not queue behind it on the in-order vmcnt.
         const int next = tile_of(round + 1);
-        if (next < ntiles) {
+        const int dbg = __builtin_amdgcn_readfirstlane((p.relu_in >> 8) & 0xff);      // A/B switches (vda_gemm_set_variant(5 + 16 * flags))
+        if ((dbg & 1) && next < ntiles) {
             set_sources(next);
-            stage(0, smem);
+            stage_a(0, 0, smem);
+            stage_a(0, 2, smem);
+            stage_w(0, smem + W_BASE);
         }
 
         // ---- epilogue. Accumulator register e of subtile (i,j) is row m = lane & 31, column 8*(e>>2) + 4*(lane>>5) + (e&3):
@@ -295,6 +351,12 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
                 if (interior) row_groups(std::false_type{});
                 else row_groups(std::true_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
+                if (i == 0 && next < ntiles && !(dbg & 1)) {
+                    set_sources(next);
+                    stage_a(0, 0, smem);
+                    stage_a(0, 2, smem);
+                    stage_w(0, smem + W_BASE);
+                }
             }
         }
         // Every wave is done with its staging slice before the next tile's stage(1) overwrites buffer 1.
@@ -305,13 +367,12 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
 
 template <int BN, int AMODE, int EPI>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
-    constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
-    constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + 8 * 8192;
+    constexpr int smem = 3 * BM * ROW_BYTES + 2 * BN * ROW_BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -327,7 +388,7 @@ int launch256(const vda_gemm_args& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI>), dim3(grid), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI>), dim3(grid), dim3(NT), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
@@ -362,4 +423,4 @@ int launch_conv(const vda_gemm_args& a, hipStream_t s) {
     return -1;                                  // caller falls back to the 128-row kernel
 }
 
-}  // namespace vda_gemm256s
+}  // namespace vda_gemm8p

@@ -157,9 +157,12 @@ struct RowAux {
     h16x8 h0, h1;
 };
 
-template <int EPI>
+// GUARD = false: the caller has established that every row / column of the wave's tile is inside the matrix. The bounds
+// test is not free: it puts every row's loads and stores in their own basic block, and hipcc then waits vmcnt(0) at each
+// (the number of stores issued so far is unknown at the join), which serialises one memory round trip per row.
+template <int EPI, bool GUARD = true>
 __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int n, RowAux& x) {
-    if (m >= p.M || n >= p.N) return;
+    if (GUARD && (m >= p.M || n >= p.N)) return;
     if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
         x.f0 = *reinterpret_cast<const f32x4*>((const float*)p.res + (size_t)m * p.ldc + n);
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
@@ -176,10 +179,10 @@ __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int 
     }
 }
 
-template <int EPI>
+template <int EPI, bool GUARD = true>
 __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n, float (&v)[8], float (&g)[8],
                                             const ColConst<8>& c, const RowAux& x) {
-    if (m >= p.M || n >= p.N) return;
+    if (GUARD && (m >= p.M || n >= p.N)) return;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] += c.bias[i];
     if constexpr (EPI == VDA_EPI_BIAS_F16) {
@@ -224,9 +227,9 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
     }
 }
 
-template <int EPI>
+template <int EPI, bool GUARD = true>
 __device__ __forceinline__ void finish_row4(const vda_gemm_args& p, int m, int n, f32x4 v, const ColConst<4>& c, const RowAux& x) {
-    if (m >= p.M || n >= p.N) return;
+    if (GUARD && (m >= p.M || n >= p.N)) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += c.bias[i];
     if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {

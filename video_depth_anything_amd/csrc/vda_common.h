@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/vda.h"
 
 typedef _Float16 h16;
@@ -50,7 +51,19 @@ __device__ __forceinline__ float erf_as(float x) {
     const float r = fmaf(-p, e, 1.0f);
     return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+// gelu(x) = 0.5 x (1 + erf(x/sqrt2)). With erf(|z|) = 1 - p(t) e^{-z^2} (same A-S 7.1.26 polynomial, 0.5 folded into its
+// coefficients, z = |x|/sqrt2 folded into t's slope and the exponent's scale):  gelu(x) = max(x, 0) - |x| * 0.5 p(t) * e^{-x^2/2}.
+// No copysign / 1+erf / 0.5x: 13 VALU issues per element instead of 17 (this runs 128x per lane per fc1 tile: ~20 % of that GEMM).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+    return fmaxf(x, 0.f) - ax * (p * t) * e;
+}
 
 // 16-byte async global -> LDS copy. The LDS destination is the wave-uniform `lds_base`
 // plus lane*16 (hardware rule); the global source is per lane.
