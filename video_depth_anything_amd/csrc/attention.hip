@@ -31,7 +31,7 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }          // 16-row conflict-free for 32-row b128 fragments
 __device__ __forceinline__ int v_swz(int row) { return ((row >> 1) & 1) << 2; }   // separates the 4 rows of a tr16 block
 
-template <bool TR>
+template <bool TR, bool PK>
 __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
                                                    int nqb, int total_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -139,25 +139,40 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
                 for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
             m_run = m_new;
         }
-        // p = exp2(s*log2e - m*log2e) on float pairs (v_pk_fma_f32 / v_pk_add_f32); raw v_exp_f32: the argument
-        // is <= 0 and flushing tiny results to zero is harmless.
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 mb2 = {m_run * LOG2E, m_run * LOG2E};
-        const f32x2 l2e = {LOG2E, LOG2E};
-        f32x2 ps2 = {0.f, 0.f};
         h16x8 pf[4];
+        if constexpr (PK) {
+            // p = exp2(s*log2e - m*log2e) on float pairs (v_pk_fma_f32 / v_pk_add_f32); raw v_exp_f32: the argument
+            // is <= 0 and flushing tiny results to zero is harmless.
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 mb2 = {m_run * LOG2E, m_run * LOG2E};
+            const f32x2 l2e = {LOG2E, LOG2E};
+            f32x2 ps2 = {0.f, 0.f};
+    #pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+    #pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 a = {s[sub][e], s[sub][e + 1]};
+                    a = a * l2e - mb2;
+                    f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    ps2 += pv;
+                    pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv[0];
+                    pf[sub * 2 + (e >> 3)][(e & 7) + 1] = (h16)pv[1];
+                }
+            l_run += ps2[0] + ps2[1];
+        } else {
+            // scalar form of the same arithmetic (A/B: v_pk_*_f32 vs two scalar issues)
+            const float mb = m_run * LOG2E;
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                f32x2 a = {s[sub][e], s[sub][e + 1]};
-                a = a * l2e - mb2;
-                f32x2 pv = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-                ps2 += pv;
-                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv[0];
-                pf[sub * 2 + (e >> 3)][(e & 7) + 1] = (h16)pv[1];
-            }
-        l_run += ps2[0] + ps2[1];
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][e], LOG2E, -mb));
+                    ps[e & 3] += pv;
+                    pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+                }
+            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        }
 
         // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
 #pragma unroll
@@ -209,10 +224,11 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
 
 }  // namespace
 
-static int g_attn_variant = 1;   // 1: ds_read_b64_tr_b16 V fragments, 0: scalar LDS reads (debug cross-check)
+static int g_attn_variant = 1;   // 1: ds_read_b64_tr_b16 V fragments + scalar softmax math (3 % faster than packed, tools/attn_one.py);
+                                 // 2: the same with v_pk_*_f32 softmax math; 0: scalar LDS reads of V (debug cross-check)
 
 extern "C" int vda_attention_set_variant(int v) {
-    g_attn_variant = v ? 1 : 0;
+    g_attn_variant = v;
     return 0;
 }
 
@@ -224,10 +240,12 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     const long long total = (long long)nqb * B * heads;
     VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (g_attn_variant)
-        hipLaunchKernelGGL((attn_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    if (g_attn_variant == 1)
+        hipLaunchKernelGGL((attn_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant)
+        hipLaunchKernelGGL((attn_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else
-        hipLaunchKernelGGL((attn_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+        hipLaunchKernelGGL((attn_kernel<false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     VDA_LAUNCH_CHECK();
     return 0;
 }

@@ -178,11 +178,15 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto mma = [&](int half, AF& fa, const WF& fw) {
+        // ReLU on the conv activation operand: in the LOAD section (after the fragments landed, before the barrier), so it
+        // runs under the partner wave's MFMA section instead of delaying this wave's
+        auto relu_a = [&](AF& fa) {
             if constexpr (AMODE == VDA_A_CONV3X3) {
 #pragma unroll
                 for (int i = 0; i < MH; ++i) fa.a[i] = __builtin_elementwise_max(fa.a[i], relu_thr);
             }
+        };
+        auto mma = [&](int half, AF& fa, const WF& fw) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MH; ++i)
@@ -221,6 +225,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             read_a(ab, 0, 0, fa);
             if (more) stage_a(kt + 2, 0, ab2);
             lgkm0();
+            relu_a(fa);
             bar();
             mma(0, fa, fw);
             bar();
@@ -228,6 +233,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             read_a(ab, 0, 1, fa);
             if (more) stage_a(kt + 2, 2, ab2);
             lgkm0();
+            relu_a(fa);
             bar();
             mma(1, fa, fw);
             bar();
@@ -235,6 +241,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             read_w(wb, 1, fw);
             read_a(ab, 1, 0, fa);
             lgkm0();
+            relu_a(fa);
             bar();
             mma(0, fa, fw);
             bar();
@@ -247,6 +254,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             lgkm0();
+            relu_a(fa);
             bar();
             mma(1, fa, fw);
             bar();
