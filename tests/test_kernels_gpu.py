@@ -395,3 +395,30 @@ def test_device_stitcher_matches_host_stitcher(n_frames, metric):
     else:
         # scale/shift: fp64 sums on the device vs numpy's fp32 sums in the closed form (its det cancels digits)
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------
+# position independence: a row's result may not depend on which tile / wave / lane / unrolled copy computes it
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("epi_name", ["BIAS_F16", "BIAS_GELU_F16", "SCALE_RES_F32", "SCALE_RES_F32_H"])
+def test_gemm_rows_are_position_independent(ops, gemm_variant, epi_name):
+    """A = [A1; A1] with 2740 rows per copy (copies sit at different offsets inside the 256-row tiles): both output halves
+    must be BIT-identical. Catches per-copy differences in instruction selection (v_fma_mix vs fma + cvt) as well as races."""
+    from video_depth_anything_amd import _lib
+    epi = getattr(_lib, "EPI_" + epi_name)
+    M1, N, K = 2740, 1024, 1024
+    A1 = rnd(M1, K, seed=60).to(F16)
+    A = dev(torch.cat([A1, A1]).contiguous())
+    W = dev(rnd(N, K, seed=61, scale=K ** -0.5).to(F16))
+    bias = dev(rnd(N, seed=62))
+    kw = dict(M=2 * M1, N=N, K=K, bias=bias)
+    if epi_name.startswith("SCALE_RES"):
+        r1 = rnd(M1, N, seed=63)
+        res = dev(torch.cat([r1, r1]).contiguous())
+        kw.update(res=res, gamma=dev(rnd(N, seed=64).abs()))
+        out = res if epi_name == "SCALE_RES_F32" else torch.zeros(2 * M1, N, dtype=F16, device="cuda")
+    else:
+        out = torch.zeros(2 * M1, N, dtype=F16, device="cuda")
+    ops.gemm(A, W, out, epi, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M1], out[M1:]), f"{int((out[:M1] != out[M1:]).sum())} elements depend on the row's position"

@@ -163,8 +163,22 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         asm volatile("" ::: "memory");
     };
 
+    // The accumulators START at the bias (MFMA C layout: register e of subtile (i, j) is column 16j + 4(lane >> 4) + e of
+    // the wave's 64): the epilogue then has no bias add and no column-constant load in front of it. The fragment of the
+    // NEXT tile is fetched with that tile's first K tile, inside the current epilogue.
+    f32x4 nbias[NJ];
+    auto load_bias = [&](int t) {
+        const int bnn = t % nbn;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = bnn * BN + wn * WTN + j * 16 + (lane >> 4) * 4;
+            nbias[j] = (p.bias != nullptr && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
+    load_bias(tile);
     set_sources(tile);
     stage_a(0, 0, smem);
     stage_a(0, 2, smem);
@@ -177,7 +191,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc[i][j] = nbias[j];
         // ReLU on the conv activation operand: in the LOAD section (after the fragments landed, before the barrier), so it
         // runs under the partner wave's MFMA section instead of delaying this wave's
         auto relu_a = [&](AF& fa) {
@@ -267,6 +281,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         const int next = tile_of(round + 1);
         const int dbg = __builtin_amdgcn_readfirstlane((p.relu_in >> 8) & 0xff);      // A/B switches (vda_gemm_set_variant(5 + 16 * flags))
         if ((dbg & 1) && next < ntiles) {
+            load_bias(next);
             set_sources(next);
             stage_a(0, 0, smem);
             stage_a(0, 2, smem);
@@ -289,7 +304,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             const int en = bn0 + c0 * 4;
             const bool geglu_idle = (EPI == VDA_EPI_GEGLU_F16) && (c0 & 7) >= 4;   // gate lanes only feed their value lanes
             vda_gemm::ColConst<NC> cc;
-            vda_gemm::load_col_const<EPI, NC>(p, en, cc);
+            vda_gemm::load_col_const<EPI, NC, false>(p, en, cc);
             constexpr int RG = RT::f32_out ? 4 : 2;                          // rows per row group
             vda_gemm::RowAux carry[RG];                                      // the next block's first group, loaded a group early
 #pragma unroll
@@ -336,7 +351,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                             const char* rp = stg + row * 256;
                             const f32x4 a = *reinterpret_cast<const f32x4*>(rp + ((c0 ^ (row & 15)) << 4));
                             if constexpr (RT::f32_out) {
-                                vda_gemm::finish_row4<EPI, GUARD>(p, bm0 + i * 32 + row, en, a, cc, aux[g & 1][q]);
+                                vda_gemm::finish_row4<EPI, GUARD, false>(p, bm0 + i * 32 + row, en, a, cc, aux[g & 1][q]);
                             } else {
                                 const f32x4 b = *reinterpret_cast<const f32x4*>(rp + (((c0 + 1) ^ (row & 15)) << 4));
                                 float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -350,7 +365,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                                         gt[4 + e] = gb[e];
                                     }
                                 }
-                                if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
+                                if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD, false>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
                             }
                         }
                     }
@@ -360,6 +375,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 else row_groups(std::true_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
                 if (i == 0 && next < ntiles && !(dbg & 1)) {
+                    load_bias(next);
                     set_sources(next);
                     stage_a(0, 0, smem);
                     stage_a(0, 2, smem);
@@ -367,8 +383,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 }
             }
         }
-        // Every wave is done with its staging slice before the next tile's stage(1) overwrites buffer 1.
-        __syncthreads();
+        // Every wave is done READING its staging slice before the next tile's K tile 1 lands in it: LDS ordering only, so a raw
+        // barrier (a __syncthreads here would also drain the stores and the prefetched K tile 0).
+        lgkm0();
+        bar();
         tile = next;
     }
 }

@@ -6,6 +6,17 @@
 
 namespace vda_gemm {
 
+// fp32 -> fp16 of an epilogue result, always as "round to fp32, then round to fp16". Left alone, hipcc fuses the last fp32
+// fma/mul of SOME elements with the conversion (v_fma_mix{lo,hi}_f16: one rounding) and not of others (v_fmac_f32 +
+// v_cvt_pk_f16_f32: two roundings) - which ones depends on the unrolled copy, so identical rows could differ by one fp16
+// ulp with their position in the tile (found by the duplicated-clip test). The empty asm makes the fp32 value opaque.
+__device__ __forceinline__ h16 to_h16(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return (h16)v;
+}
+
 template <int EPI>
 __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, f32x4 v, f32x4 g) {
     // v: accumulators for columns n..n+3 of row m (g: gate accumulators, GEGLU only).
@@ -20,7 +31,7 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        h16x4 o = {to_h16(v[0]), to_h16(v[1]), to_h16(v[2]), to_h16(v[3])};
         *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + n) = o;
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
         if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
@@ -37,7 +48,7 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] += (float)r2[i];
         }
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        h16x4 o = {to_h16(v[0]), to_h16(v[1]), to_h16(v[2]), to_h16(v[3])};
         *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
     } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
         // n indexes the interleaved weight rows [16 value | 16 gate] per 32; g belongs to n + 16.
@@ -45,7 +56,7 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
         const int oc = (n >> 5) * 16 + (n & 15);
         h16x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (h16)(v[i] * gelu_erf(g[i]));
+        for (int i = 0; i < 4; ++i) o[i] = to_h16(v[i] * gelu_erf(g[i]));
         *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + oc) = o;
     } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
         const int f = m / p.P, q = m - f * p.P;
@@ -60,7 +71,7 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / p.tW, x = rem - y * p.tW;
         const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)x * k + kx;
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        h16x4 o = {to_h16(v[0]), to_h16(v[1]), to_h16(v[2]), to_h16(v[3])};
         *reinterpret_cast<h16x4*>((h16*)p.out + orow * p.ldc + co) = o;
     } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
         *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
@@ -68,7 +79,7 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
         if (p.gamma) v *= *reinterpret_cast<const f32x4*>(p.gamma + n);
         const size_t off = (size_t)m * p.ldc + n;
         v += *reinterpret_cast<const f32x4*>((const float*)p.res + off);
-        h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+        h16x4 o = {to_h16(v[0]), to_h16(v[1]), to_h16(v[2]), to_h16(v[3])};
         *reinterpret_cast<h16x4*>((h16*)p.out + off) = o;
     }
 }
@@ -97,7 +108,7 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
 __device__ __forceinline__ void store8h(h16* p, const float (&v)[8]) {
     h16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (h16)v[i];
+    for (int i = 0; i < 8; ++i) o[i] = to_h16(v[i]);
     *reinterpret_cast<h16x8*>(p) = o;
 }
 
@@ -109,7 +120,8 @@ struct ColConst {
     float gbias[NC];     // GEGLU: bias of the gate columns n+16..
 };
 
-template <int EPI, int NC>
+// BIAS = false: the kernel started its accumulators at the bias (the 8-phase kernel does), so the epilogue neither loads nor adds it.
+template <int EPI, int NC, bool BIAS = true>
 __device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, ColConst<NC>& c) {
     const bool ok = n < p.N;
 #pragma unroll
@@ -119,7 +131,7 @@ __device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, Co
         c.gbias[i] = 0.f;
     }
     if (!ok) return;
-    if (p.bias) {
+    if (BIAS && p.bias) {
 #pragma unroll
         for (int i = 0; i < NC; i += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n + i);
@@ -179,12 +191,14 @@ __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int 
     }
 }
 
-template <int EPI, bool GUARD = true>
+template <int EPI, bool GUARD = true, bool BIAS = true>
 __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n, float (&v)[8], float (&g)[8],
                                             const ColConst<8>& c, const RowAux& x) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
+    if constexpr (BIAS) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] += c.bias[i];
+        for (int i = 0; i < 8; ++i) v[i] += c.bias[i];
+    }
     if constexpr (EPI == VDA_EPI_BIAS_F16) {
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
@@ -206,14 +220,14 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            v[i] = x.f0[i] + c.gamma[i] * v[i];
-            v[4 + i] = x.f1[i] + c.gamma[4 + i] * v[4 + i];
+            v[i] = fmaf(c.gamma[i], v[i], x.f0[i]);                 // explicit fma: identical rounding in every instantiation
+            v[4 + i] = fmaf(c.gamma[4 + i], v[4 + i], x.f1[i]);
         }
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
         // n is a VALUE column group (n % 32 < 16); g holds columns n+16.. (the gates)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf(g[i] + c.gbias[i]);
+        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf(BIAS ? g[i] + c.gbias[i] : g[i]);
         store8h((h16*)p.out + (size_t)m * p.ldc + ((n >> 5) * 16 + (n & 15)), v);
     } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
         const int k = p.tK, Co = p.tCout;
@@ -227,14 +241,16 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
     }
 }
 
-template <int EPI, bool GUARD = true>
+template <int EPI, bool GUARD = true, bool BIAS = true>
 __device__ __forceinline__ void finish_row4(const vda_gemm_args& p, int m, int n, f32x4 v, const ColConst<4>& c, const RowAux& x) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
+    if constexpr (BIAS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] += c.bias[i];
+        for (int i = 0; i < 4; ++i) v[i] += c.bias[i];
+    }
     if constexpr (EPI == VDA_EPI_SCALE_RES_F32) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = x.f0[i] + c.gamma[i] * v[i];
+        for (int i = 0; i < 4; ++i) v[i] = fmaf(c.gamma[i], v[i], x.f0[i]);   // explicit fma: identical rounding in every instantiation
         *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;
     } else if constexpr (EPI == VDA_EPI_BIAS_F32) {
         *reinterpret_cast<f32x4*>((float*)p.out + (size_t)m * p.ldc + n) = v;

@@ -62,7 +62,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
     p = fmaf(p, t, 0.5f * -0.284496736f);
     p = fmaf(p, t, 0.5f * 0.254829592f);
     const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    return fmaxf(x, 0.f) - ax * (p * t) * e;
+    // explicit fma: the guarded and the branch-free epilogue instantiations must round identically (a row's result may not
+    // depend on which tile it falls in), so nothing is left to -ffp-contract's per-instance choice
+    return fmaf(-(ax * (p * t)), e, fmaxf(x, 0.f));
 }
 
 // 16-byte async global -> LDS copy. The LDS destination is the wave-uniform `lds_base`
