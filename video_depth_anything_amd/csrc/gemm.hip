@@ -206,6 +206,7 @@ int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 // gemm8p_*.hip: 256 x 256 tile, 8-phase two-group schedule
 int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_conv_bn256(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm8p_dense_bn256_sched(const vda_gemm_args& a, hipStream_t s, int sched);
 
 static int vda_gemm256s_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
     if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256s_dense_bn256(a, s) : vda_gemm256s_dense_bn128(a, s);
@@ -302,7 +303,8 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     if (big) {
         vda_gemm_args a8 = a;
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
-        const int rc = eight ? (a.a_mode == VDA_A_DENSE ? vda_gemm8p_dense_bn256(a8, s) : vda_gemm8p_conv_bn256(a8, s))
+        const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
+        const int rc = eight ? (a.a_mode == VDA_A_DENSE ? (sched8 ? vda_gemm8p_dense_bn256_sched(a8, s, sched8) : vda_gemm8p_dense_bn256(a8, s)) : vda_gemm8p_conv_bn256(a8, s))
                              : small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s);
         if (rc >= 0) {
             // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>

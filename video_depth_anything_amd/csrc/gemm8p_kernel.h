@@ -10,10 +10,11 @@
 //     MFMA section its partner is in its load section, so the DMA issue cost (60..185 cycles per 1-KiB piece, measured in
 //     MI355X_MICROARCH.md) and the LDS reads never hold the matrix pipe. In the one-barrier-per-K-tile kernel both waves of
 //     a SIMD issue their 8-piece DMA burst at the same moment (skipping the DMA there saves 24 %).
-//   * LDS-DMA stays in flight across barriers: raw s_barrier, counted s_waitcnt vmcnt(8) once per K tile (phase 4) instead
+//   * LDS-DMA stays in flight across barriers: raw s_barrier, counted s_waitcnt vmcnt(6) once per K tile (phase 4) instead
 //     of vmcnt(0) + __syncthreads. A is triple-buffered (3 x 32 KiB), W double-buffered (2 x 32 KiB) = 160 KiB: A(kt+2)
-//     is issued in phases 1-2 of K tile kt (2 + 2 pieces per wave), W(kt+2) in phase 4 (its slot is K tile kt's own,
-//     last read in phase 3), so every piece has at least a whole K tile of MFMA time to land.
+//     is issued in phases 2-3 of K tile kt, W(kt+2) half in phase 4 (its slot is K tile kt's own, last read in phase 3) and
+//     half in phase 1 of K tile kt+1: two pieces per wave and phase, every piece has at least 3 phases of MFMA time to land
+//     (SCHED 0 keeps the 2/2/0/4 form with vmcnt(8) and 4 phases of cover for A/B).
 //
 // Ordering rules followed (cdna_hip_programming.md, "The 256^2 8-phase template"):
 //   RAW: a wave's counted vmcnt precedes its phase-4 barrier; K tile kt+1 is first read in phase 1 of the next K tile, i.e.
@@ -31,7 +32,7 @@ constexpr int BM = 256;
 constexpr int NW = 8;                 // waves
 constexpr int NT = NW * 64;
 
-template <int BN, int AMODE, int EPI>
+template <int BN, int AMODE, int EPI, int SCHED = 1>
 __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
     constexpr int WM = NW / WN;                    // waves along M
@@ -111,10 +112,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
         }
     };
-    auto stage_w = [&](int kt, char* wbuf) {
+    auto stage_w = [&](int kt, char* wbuf, int j0 = 0, int j1 = 4) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int j = 0; j < WJ; ++j) {
+        for (int j = j0; j < j1; ++j) {
             const int n = min(tn0 + (wave + NW * j) * 8 + lrow, p.N - 1);
             glds16((const h16*)p.W + (size_t)(unsigned)(n * p.K + src_chk + k0), wbuf + (wave + NW * j) * 1024);
         }
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
         };
         auto mma = [&](int half, AF& fa, const WF& fw) {
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (SCHED != 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < MH; ++i)
 #pragma unroll
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                     if (half == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[i][j], 0, 0, 0);
                     else acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[MH + i][j], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (SCHED != 2) __builtin_amdgcn_s_setprio(0);
         };
 
         // K tile 0 of this tile (A slot 0, W slot 0) was issued before the previous tile's epilogue (or above).
@@ -219,8 +220,13 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         if (nt > 1) {                           // K tile 1 -> A slot 1 (the epilogue staging area: released by the tile-end barrier)
             stage_a(1, 0, smem + A_BYTES);
             stage_a(1, 2, smem + A_BYTES);
-            stage_w(1, smem + W_BASE + W_BYTES);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // K tile 0 landed (mine); K tile 1 stays in flight
+            if constexpr (SCHED == 1) {
+                stage_w(1, smem + W_BASE + W_BYTES, 0, 2);          // W rows 128.. of K tile 1 follow in phase 1
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                stage_w(1, smem + W_BASE + W_BYTES);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile 0 landed (mine); K tile 1 stays in flight
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -234,44 +240,86 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             const int sa2 = sa == 0 ? 2 : sa - 1;                   // (kt + 2) % 3
             char* ab2 = smem + sa2 * A_BYTES;
             const bool more = kt + 2 < nt;
-            // phase 1: k-step 0, rows lo
-            read_w(wb, 0, fw);
-            read_a(ab, 0, 0, fa);
-            if (more) stage_a(kt + 2, 0, ab2);
-            lgkm0();
-            relu_a(fa);
-            bar();
-            mma(0, fa, fw);
-            bar();
-            // phase 2: k-step 0, rows hi
-            read_a(ab, 0, 1, fa);
-            if (more) stage_a(kt + 2, 2, ab2);
-            lgkm0();
-            relu_a(fa);
-            bar();
-            mma(1, fa, fw);
-            bar();
-            // phase 3: k-step 1, rows lo (last read of this K tile's W slot)
-            read_w(wb, 1, fw);
-            read_a(ab, 1, 0, fa);
-            lgkm0();
-            relu_a(fa);
-            bar();
-            mma(0, fa, fw);
-            bar();
-            // phase 4: k-step 1, rows hi (last read of this K tile's A slot); W(kt+2) into the W slot just released
-            read_a(ab, 1, 1, fa);
-            if (more) {
-                stage_w(kt + 2, const_cast<char*>(wb));
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile kt+1 landed; A(kt+2), W(kt+2) stay in flight
+            if constexpr (SCHED == 1) {
+                // DEFAULT: 2 DMA pieces per phase - W(kt+1) rows 128.. | A(kt+2) rows ..127 | A(kt+2) rows 128.. | W(kt+2) rows ..127 -
+                // and vmcnt(6): even issue load, 3 phases of minimum cover. In-process A/B vs the 2/2/0/4 + vmcnt(8) form below
+                // (SCHED 0, 4 phases of cover): -0.6..-3 % on every encoder shape.
+                char* wb1 = smem + W_BASE + ((kt + 1) & 1) * W_BYTES;
+                read_w(wb, 0, fw);
+                read_a(ab, 0, 0, fa);
+                if (kt + 1 < nt) stage_w(kt + 1, wb1, 2, 4);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(0, fa, fw);
+                bar();
+                read_a(ab, 0, 1, fa);
+                if (more) stage_a(kt + 2, 0, ab2);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(1, fa, fw);
+                bar();
+                read_w(wb, 1, fw);
+                read_a(ab, 1, 0, fa);
+                if (more) stage_a(kt + 2, 2, ab2);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(0, fa, fw);
+                bar();
+                read_a(ab, 1, 1, fa);
+                if (more) {
+                    stage_w(kt + 2, const_cast<char*>(wb), 0, 2);
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(1, fa, fw);
+                bar();
             } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // phase 1: k-step 0, rows lo
+                read_w(wb, 0, fw);
+                read_a(ab, 0, 0, fa);
+                if (more) stage_a(kt + 2, 0, ab2);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(0, fa, fw);
+                bar();
+                // phase 2: k-step 0, rows hi
+                read_a(ab, 0, 1, fa);
+                if (more) stage_a(kt + 2, 2, ab2);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(1, fa, fw);
+                bar();
+                // phase 3: k-step 1, rows lo (last read of this K tile's W slot)
+                read_w(wb, 1, fw);
+                read_a(ab, 1, 0, fa);
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(0, fa, fw);
+                bar();
+                // phase 4: k-step 1, rows hi (last read of this K tile's A slot); W(kt+2) into the W slot just released
+                read_a(ab, 1, 1, fa);
+                if (more) {
+                    stage_w(kt + 2, const_cast<char*>(wb));
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile kt+1 landed; A(kt+2), W(kt+2) stay in flight
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                lgkm0();
+                relu_a(fa);
+                bar();
+                mma(1, fa, fw);
+                bar();
             }
-            lgkm0();
-            relu_a(fa);
-            bar();
-            mma(1, fa, fw);
-            bar();
             sa = sa == 2 ? 0 : sa + 1;
         }
         if (wm == 0) bar();                     // re-align the two groups: every wave is past its last MFMA section's reads
@@ -391,14 +439,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     }
 }
 
-template <int BN, int AMODE, int EPI>
+template <int BN, int AMODE, int EPI, int SCHED = 1>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int smem = 3 * BM * ROW_BYTES + 2 * BN * ROW_BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     static int num_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) {
             vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -414,7 +462,7 @@ int launch256(const vda_gemm_args& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI>), dim3(grid), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED>), dim3(grid), dim3(NT), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
