@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """CLI with the reference's flags and defaults (/root/reference/run.py:24-34) over the MI355X engine.
 
-Video codec I/O (utils/dc_utils.py) is outside the accelerated path: `--input_video`
-may be an .npy / .npz (key `frames`) of uint8 [N,H,W,3] RGB frames, or a video file when decord or cv2 is
-importable. Depth is written as <name>_depths.npz (always when no encoder is available for the mp4s).
+Frame I/O is utils/dc_utils.py (same two helpers as the reference's): `--input_video` may be an .npy / .npz (key `frames`)
+of uint8 [N,H,W,3] RGB frames, a directory of images, a GIF, or a video file when decord or cv2 is importable; the
+visualisations are mp4 through imageio when present and animated GIFs otherwise; `--save_npz` adds <name>_depths.npz.
 `--metric` selects the metric-depth variant (metric_depth/run.py: ViT-L, no scale/shift alignment).
 """
 import argparse
@@ -12,44 +12,8 @@ import os
 import numpy as np
 import torch
 
+from utils.dc_utils import read_video_frames, save_video
 from video_depth_anything_amd.video_depth import MetricVideoDepthAnything, VideoDepthAnything
-
-
-def read_frames(path, process_length, target_fps, max_res):
-    ext = os.path.splitext(path)[1].lower()
-    if ext == ".npy":
-        frames, fps = np.load(path), 24
-    elif ext == ".npz":
-        z = np.load(path)
-        frames, fps = z["frames"], float(z["fps"]) if "fps" in z else 24
-    else:
-        try:
-            from decord import VideoReader, cpu
-            vr = VideoReader(path, ctx=cpu(0))
-            fps = vr.get_avg_fps()
-            frames = vr.get_batch(list(range(len(vr)))).asnumpy()
-        except ImportError:
-            try:
-                import cv2
-            except ImportError as e:
-                raise SystemExit("no video decoder (decord/cv2) in this environment: pass frames as .npy/.npz") from e
-            cap = cv2.VideoCapture(path)
-            fps = cap.get(cv2.CAP_PROP_FPS)
-            out = []
-            while True:
-                ok, f = cap.read()
-                if not ok:
-                    break
-                out.append(cv2.cvtColor(f, cv2.COLOR_BGR2RGB))
-            frames = np.stack(out)
-    if process_length > 0:
-        frames = frames[:process_length]
-    if target_fps > 0 and target_fps < fps:
-        stride = max(round(fps / target_fps), 1)
-        frames, fps = frames[::stride], fps / stride
-    if max_res > 0 and max(frames.shape[1:3]) > max_res:
-        raise SystemExit(f"frames larger than --max_res {max_res}: down-scale them before calling (no cv2 here)")
-    return np.ascontiguousarray(frames, dtype=np.uint8), fps
 
 
 if __name__ == '__main__':
@@ -86,23 +50,16 @@ if __name__ == '__main__':
     video_depth_anything.load_state_dict(sd, strict=True)
     video_depth_anything = video_depth_anything.to(DEVICE).eval()
 
-    frames, target_fps = read_frames(args.input_video, args.max_len, args.target_fps, args.max_res)
+    frames, target_fps = read_video_frames(args.input_video, args.max_len, args.target_fps, args.max_res)   # run.py:53
     depths, fps = video_depth_anything.infer_video_depth(frames, target_fps, input_size=args.input_size, device=DEVICE, fp32=args.fp32)
 
     video_name = os.path.basename(args.input_video)
     os.makedirs(args.output_dir, exist_ok=True)
     stem = os.path.join(args.output_dir, os.path.splitext(video_name)[0])
-    wrote_video = False
-    try:
-        import imageio
-        d_min, d_max = depths.min(), depths.max()           # utils/dc_utils.py:75-80: global min/max -> uint8
-        vis = ((depths - d_min) / max(d_max - d_min, 1e-12) * 255).astype(np.uint8)
-        imageio.mimwrite(stem + '_src.mp4', frames, fps=fps)
-        imageio.mimwrite(stem + '_vis.mp4', np.repeat(vis[..., None], 3, -1), fps=fps)
-        wrote_video = True
-    except Exception:
-        pass
-    if args.save_npz or not wrote_video:
+    # run.py:57-62: <name>_src.mp4 and <name>_vis.mp4 (GIFs when no H.264 encoder is importable)
+    src_path = save_video(frames, stem + '_src.mp4', fps=fps)
+    vis_path = save_video(depths, stem + '_vis.mp4', fps=fps, is_depths=True, grayscale=args.grayscale)
+    if args.save_npz:
         np.savez_compressed(stem + '_depths.npz', depths=depths)
     if args.save_exr:
         import Imath
@@ -115,4 +72,4 @@ if __name__ == '__main__':
             f = OpenEXR.OutputFile(f"{exr_dir}/frame_{i:05d}.exr", header)
             f.writePixels({"Z": depth.tobytes()})
             f.close()
-    print(f"{depths.shape[0]} frames -> {stem}_depths.npz" if not wrote_video else f"wrote {stem}_vis.mp4")
+    print(f"{depths.shape[0]} frames -> {vis_path}" + (f", {stem}_depths.npz" if args.save_npz else ""))

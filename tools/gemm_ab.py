@@ -9,7 +9,7 @@ epi = int(sys.argv[2]) if len(sys.argv) > 2 else _lib.EPI_BIAS_F16
 shapes = [(43840, 4096, 1024), (43840, 1024, 4096), (43840, 3072, 1024), (43840, 1024, 1024)]
 conv = len(sys.argv) > 3 and sys.argv[3] == "conv"
 if conv:      # head convs: 3x3, 256 -> 256 channels on 32 frames of 148^2 / 74^2 / 37^2
-    shapes = [(32 * 148 * 148, 256, 2304), (32 * 74 * 74, 256, 2304), (32 * 37 * 37, 256, 2304)]
+    shapes = [(32 * 148 * 148, 256, 2304), (32 * 74 * 74, 256, 2304), (32 * 37 * 37, 256, 2304), (32 * 296 * 296, 128, 2304)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for (M, N, K) in shapes:
     A = torch.randn(M, K if not conv else K // 9, device="cuda", generator=g).half()
