@@ -111,6 +111,8 @@ int vda_attention_set_variant(int v);
  * motion_module/attention.py:182-211): qkv fp16 [T*hw, 3*C] frame-major rows,
  * 8 heads of d = C/8 -> out fp16 [T*hw, C]. Batch b>1 is expressed by calling per clip. */
 int vda_temporal_attention_f16(const void* qkv, void* out, int T, int hw, int C, int heads, vda_stream_t stream);
+/* 1 (default): MFMA kernel for head dims 32 / 64 / 128, VALU kernel otherwise; 0: VALU kernel everywhere (cross-check). */
+int vda_temporal_attention_set_variant(int v);
 
 /* ---------------------------------------------------------------- resampling / layout
  * Bilinear, align_corners=True (util/blocks.py:156-158, dpt_temporal.py:94-96,

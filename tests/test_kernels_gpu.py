@@ -259,12 +259,19 @@ def test_attention_spiked_scores(ops):
     close(out, attn_ref(qkv, B, N, H), rtol=3e-3, atol=3e-3, what="attention spiked")
 
 
-@pytest.mark.parametrize("Cc,T,hw", [(64, 32, 10), (64, 4, 12), (128, 7, 5), (192, 32, 6), (384, 32, 3), (256, 32, 4), (1024, 32, 3)])
-def test_temporal_attention(ops, Cc, T, hw):
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("Cc,T,hw", [(64, 32, 10), (64, 4, 12), (128, 7, 5), (192, 32, 6), (384, 32, 3), (256, 32, 4), (256, 5, 7), (512, 19, 3), (1024, 32, 3),
+                                     (1024, 9, 2)])
+def test_temporal_attention(ops, Cc, T, hw, variant):
+    from video_depth_anything_amd._lib import lib
     heads, d = 8, Cc // 8
     qkv = rnd(T * hw, 3 * Cc, seed=45).to(F16)
     out = torch.full((T * hw, Cc), float("nan"), dtype=F16, device="cuda")
-    ops.temporal_attention(dev(qkv), out, T, hw, Cc)
+    lib.vda_temporal_attention_set_variant(variant)          # 1: MFMA kernel for d = 32 / 64 / 128, 0: VALU kernel
+    try:
+        ops.temporal_attention(dev(qkv), out, T, hw, Cc)
+    finally:
+        lib.vda_temporal_attention_set_variant(1)
     x = qkv.float().reshape(T, hw, 3, heads, d).permute(2, 1, 3, 0, 4)      # [3, hw, heads, T, d]
     a = (x[0] @ x[1].transpose(-1, -2) * d ** -0.5).softmax(dim=-1)
     ref = (a @ x[2]).permute(2, 0, 1, 3).reshape(T * hw, Cc)

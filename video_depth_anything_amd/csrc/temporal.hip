@@ -4,7 +4,11 @@
 // loads of the frame-major [T*hw, 3C] rows (no "(b f) d c -> (b d) f c" transpose is ever
 // materialised) and does its 32x32 score blocks on the VALU out of LDS.
 //
-// Workgroup = one pixel x `hg` heads (hg*d <= 256 channels). Wave work item = (head, 16 queries):
+// Two kernels. Head dims 32 / 64 / 128 (ViT-L: 1024/8 and 256/8) run on MFMA (tattn_mfma_kernel below): one WAVE per
+// (pixel, head), the spatial attention's single-tile case - S^T = K.Q^T with the query on the lane, in-lane softmax + one
+// lane^32 exchange, the exponentiated accumulators reused in place as the B operand of O^T = V^T.P^T, V^T by
+// ds_read_b64_tr_b16 - 16 + 2D/16... MFMAs instead of ~2000 VALU MACs per lane. Other head dims (ViT-S: 24, 48, 8) keep the
+// VALU kernel: workgroup = one pixel x `hg` heads (hg*d <= 256 channels). Wave work item = (head, 16 queries):
 // lane (i = l&15, jq = l>>4) owns query i and keys 8jq..8jq+7; softmax is 8 in-lane values + two
 // cross-lane exchanges; P goes through a per-wave LDS scratch so each lane can then produce d/4
 // output channels of its query.
@@ -109,6 +113,136 @@ __global__ void __launch_bounds__(256) tattn_kernel(const h16* __restrict__ qkv,
     }
 }
 
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// ---- MFMA form: one wave per (pixel, head), 4 heads per workgroup, no cross-wave traffic (each wave stages, computes and
+// stores its own head, so LDS ordering is the wave's own lgkmcnt).
+//   LDS per wave: q (later v) and k as [32 frames][D channels] fp16 rows of 2D + 32 bytes (the 32-byte pad shifts consecutive rows by 8
+//   banks: conflict-free for the 32-row ds_read_b128 fragments and for the 4-row ds_read_b64_tr_b16 blocks).
+template <int D>
+__global__ void __launch_bounds__(256) tattn_mfma_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int T, int hw, int C, int heads) {
+    constexpr int RSB = 2 * D + 32;                           // row bytes
+    constexpr int TEN = TMAX * RSB;                          // one tensor of one head
+    extern __shared__ __attribute__((aligned(16))) char smem_t[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x, head = blockIdx.y * 4 + wave;
+    if (head >= heads) return;                               // wave-uniform; no workgroup barrier below
+    char* base = smem_t + wave * 2 * TEN;
+
+    // ---- stage q, k of (pixel, head): 16-byte loads, D/8 lanes per (frame, tensor) segment. v is fetched now but parked in
+    // registers: it takes q's LDS rows once the scores are done (2 tensors of LDS per wave instead of 3: 5 -> 8 waves per CU at D = 128).
+    constexpr int VPS = D / 8;                                // 16-byte vectors per segment
+    constexpr int SPI = 64 / VPS;                            // segments per wave instruction
+    constexpr int NIT = TMAX / SPI;                          // instructions per tensor
+    const int sv = lane % VPS, ss = lane / VPS;
+    h16x8 vreg[NIT];
+    {
+#pragma unroll
+        for (int it = 0; it < 2 * NIT; ++it) {
+            const int seg = it * SPI + ss;                   // seg = which * 32 + frame
+            const int which = seg >> 5, f = seg & 31;
+            h16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (f < T) x = *reinterpret_cast<const h16x8*>(qkv + ((size_t)f * hw + p) * (3 * (size_t)C) + which * C + head * D + sv * 8);
+            *reinterpret_cast<h16x8*>(base + which * TEN + f * RSB + sv * 16) = x;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int f = it * SPI + ss;
+            vreg[it] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (f < T) vreg[it] = *reinterpret_cast<const h16x8*>(qkv + ((size_t)f * hw + p) * (3 * (size_t)C) + 2 * C + head * D + sv * 8);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    const int r = lane & 31, h = lane >> 5;
+    const char* qb = base;
+    const char* kb = base + TEN;
+    const char* vb = base;                                  // v replaces q after the scores
+
+    // ---- S^T[key][query] = K . Q^T
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < D / 16; ++ks) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(kb + r * RSB + (ks * 16 + h * 8) * 2);
+        const h16x8 qf = *reinterpret_cast<const h16x8*>(qb + r * RSB + (ks * 16 + h * 8) * 2);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf, s, 0, 0, 0);
+    }
+    // q's rows are consumed (the MFMAs above have read their operands once they issue; lgkmcnt covers the reads): park v there
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) *reinterpret_cast<h16x8*>(base + (it * SPI + ss) * RSB + sv * 16) = vreg[it];
+    // register e is key (e&3) + 8*(e>>2) + 4h of query r
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float c2 = rsqrtf((float)D) * LOG2E;
+    float mx = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int key = (e & 3) + 8 * (e >> 2) + 4 * h;
+        s[e] = key < T ? s[e] * c2 : -1e30f;
+        mx = fmaxf(mx, s[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    h16x8 pf[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(s[e] - mx);
+        sum += pv;
+        pf[e >> 3][e & 7] = (h16)pv;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // v rows written (own wave) before the transposed reads
+    // ---- O^T[ch][query] = V^T . P^T: 2 steps of 16 keys per 32-channel block (k order of pf: key 16s + 8(j>>2) + 4h + (j&3))
+    const int i = lane & 15, qq = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int c = 0; c < D / 32; ++c) {
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        const int col = c * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+#pragma unroll
+        for (int kstep = 0; kstep < 2; ++kstep) {
+            h16x8 vf;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int key = kstep * 16 + half * 8 + 4 * h + qq;
+                const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((VDA_LDS_AS fp16x4_t*)(vb + key * RSB + col * 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vf[half * 4 + e] = (h16)v4[e];
+            }
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], o, 0, 0, 0);
+        }
+        // lane holds query (frame) r, channels c*32 + (e&3) + 8*(e>>2) + 4h
+        if (r < T) {
+            h16* op = out + ((size_t)r * hw + p) * C + head * D + c * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 ov = {(h16)(o[4 * g + 0] * inv), (h16)(o[4 * g + 1] * inv), (h16)(o[4 * g + 2] * inv), (h16)(o[4 * g + 3] * inv)};
+                *reinterpret_cast<h16x4*>(op + 8 * g) = ov;
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_tattn_mfma(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipStream_t s) {
+    constexpr size_t smem = (size_t)4 * 2 * TMAX * (2 * D + 32);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tattn_mfma_kernel<D>), dim3(hw, (heads + 3) / 4), dim3(256), smem, s, qkv, out, T, hw, C, heads);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int D>
 int launch_tattn(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipStream_t s) {
     int hg = 1;
@@ -127,6 +261,13 @@ int launch_tattn(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipS
 
 }  // namespace
 
+static int g_tattn_variant = 1;   // 1: MFMA kernel for head dims 32/64/128; 0: VALU kernel everywhere (A/B, cross-check)
+
+extern "C" int vda_temporal_attention_set_variant(int v) {
+    g_tattn_variant = v;
+    return 0;
+}
+
 extern "C" int vda_temporal_attention_f16(const void* qkv, void* out, int T, int hw, int C, int heads, vda_stream_t stream) {
     VDA_REQUIRE(qkv && out, "vda_temporal_attention: null pointer");
     VDA_REQUIRE(T > 0 && T <= TMAX, "vda_temporal_attention: T=%d must be in 1..%d", T, TMAX);
@@ -135,6 +276,14 @@ extern "C" int vda_temporal_attention_f16(const void* qkv, void* out, int T, int
     const h16* q = (const h16*)qkv;
     h16* o = (h16*)out;
     hipStream_t s = (hipStream_t)stream;
+    if (g_tattn_variant) {
+        switch (C / heads) {                     // MFMA form
+            case 32: return launch_tattn_mfma<32>(q, o, T, hw, C, heads, s);
+            case 64: return launch_tattn_mfma<64>(q, o, T, hw, C, heads, s);
+            case 128: return launch_tattn_mfma<128>(q, o, T, hw, C, heads, s);
+            default: break;
+        }
+    }
     switch (C / heads) {
         case 8: return launch_tattn<8>(q, o, T, hw, C, heads, s);
         case 16: return launch_tattn<16>(q, o, T, hw, C, heads, s);
