@@ -20,7 +20,7 @@ for (M, N, K) in shapes:
     kw = dict(M=M, N=N, K=K, bias=bias)
     if conv:
         hw = int(round((M // 32) ** 0.5))
-        kw.update(conv=(32, hw, hw, K // 9, hw, hw, 1), relu_in=True)
+        kw.update(conv=(32, hw, hw, K // 9, hw, hw, 1), relu_in=os.environ.get("AB_RELU", "1") == "1")
         if epi == _lib.EPI_RES_F16:
             kw.update(res=torch.randn(M, N, device="cuda", generator=g).half())
     if epi in (_lib.EPI_SCALE_RES_F32,):

@@ -89,6 +89,26 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     };
 
     // A pieces j = 2h, 2h+1 of a wave lie in rows [128h, 128h + 128): the half read by wave group h.
+    // conv: which 3x3 tap and which 64-channel slice K tile kt is. A division by the runtime channel count: used at the tile
+    // seams only - inside the K loop the pair is advanced incrementally (a ~40-instruction dependent chain in a load section
+    // outlasts the partner's MFMA section: the 8-phase conv was 16 % slower than the one-barrier kernel because of it).
+    int cv_tap = 0, cv_ci0 = 0;
+    auto tap_of = [&](int kt) {
+        if constexpr (AMODE == VDA_A_CONV3X3) {
+            const int k0 = kt * BK;
+            cv_tap = k0 / p.cCin;
+            cv_ci0 = k0 - cv_tap * p.cCin;
+        }
+    };
+    auto tap_next = [&]() {
+        if constexpr (AMODE == VDA_A_CONV3X3) {
+            cv_ci0 += BK;
+            if (cv_ci0 >= p.cCin) {
+                cv_ci0 = 0;
+                ++cv_tap;
+            }
+        }
+    };
     auto stage_a = [&](int kt, int j0, char* abuf) {
         const int k0 = kt * BK;
         if constexpr (AMODE == VDA_A_DENSE) {
@@ -99,8 +119,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), abuf + (wave + NW * j) * 1024);
             }
         } else {
-            const int tap = k0 / p.cCin, ci0 = k0 - tap * p.cCin;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int tap = cv_tap, ci0 = cv_ci0;            // set by tap_of(kt) / tap_next()
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap = 0..8
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = j0 + jj;
@@ -181,6 +201,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     if (tile >= ntiles) return;                        // uniform per workgroup
     load_bias(tile);
     set_sources(tile);
+    tap_of(0);
     stage_a(0, 0, smem);
     stage_a(0, 2, smem);
     stage_w(0, smem + W_BASE);
@@ -218,6 +239,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         WF fw;
         if (round > 0) set_sources(tile);       // recomputed rather than kept live across the epilogue
         if (nt > 1) {                           // K tile 1 -> A slot 1 (the epilogue staging area: released by the tile-end barrier)
+            tap_of(1);
             stage_a(1, 0, smem + A_BYTES);
             stage_a(1, 2, smem + A_BYTES);
             if constexpr (SCHED == 1) {
@@ -234,6 +256,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         if (wm == 1) bar();                     // waves 4..7 run one barrier behind from here to the end of the K loop
 
         int sa = 0;                             // A slot of K tile kt (kt % 3)
+        tap_of(2);                              // conv: (tap, channel slice) of the next K tile to stage, advanced per K tile
         for (int kt = 0; kt < nt; ++kt) {
             const char* ab = smem + sa * A_BYTES;
             const char* wb = smem + W_BASE + (kt & 1) * W_BYTES;
@@ -262,7 +285,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 bar();
                 read_w(wb, 1, fw);
                 read_a(ab, 1, 0, fa);
-                if (more) stage_a(kt + 2, 2, ab2);
+                if (more) {
+                    stage_a(kt + 2, 2, ab2);
+                    tap_next();
+                }
                 lgkm0();
                 relu_a(fa);
                 bar();
@@ -292,7 +318,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 bar();
                 // phase 2: k-step 0, rows hi
                 read_a(ab, 0, 1, fa);
-                if (more) stage_a(kt + 2, 2, ab2);
+                if (more) {
+                    stage_a(kt + 2, 2, ab2);
+                    tap_next();
+                }
                 lgkm0();
                 relu_a(fa);
                 bar();
@@ -331,6 +360,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         if ((dbg & 1) && next < ntiles) {
             load_bias(next);
             set_sources(next);
+            tap_of(0);
             stage_a(0, 0, smem);
             stage_a(0, 2, smem);
             stage_w(0, smem + W_BASE);
@@ -425,6 +455,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 if (i == 0 && next < ntiles && !(dbg & 1)) {
                     load_bias(next);
                     set_sources(next);
+                    tap_of(0);
                     stage_a(0, 0, smem);
                     stage_a(0, 2, smem);
                     stage_w(0, smem + W_BASE);
