@@ -95,12 +95,29 @@ class VideoDepthAnything:
         plan = plan_windows(n)
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
-        video = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)          # the whole uint8 video, uploaded ONCE
+        # The uint8 video lives in HBM and every frame crosses PCIe ONCE - but not all up front: the prefix a window needs is
+        # uploaded on a side stream while the previous window computes (window k reads frames <= 22k + 31 only).
+        frames = np.ascontiguousarray(frames)
+        host = torch.from_numpy(frames)
+        video = torch.empty((n, H0, W0, 3), dtype=torch.uint8, device=dev)
+        compute = torch.cuda.current_stream(dev)
+        upload = torch.cuda.Stream(device=dev)
+        resident = [0]                                                          # frames [0, resident) are on the device
+
+        def ensure(upto):
+            upto = min(upto, n)
+            if upto > resident[0]:
+                with torch.cuda.stream(upload):
+                    video[resident[0]:upto].copy_(host[resident[0]:upto], non_blocking=True)
+                resident[0] = upto
+
         xin = torch.empty(1, INFER_LEN, 3, H0, W0, dtype=torch.float32, device=dev)
 
-        def window_depth(idxs, out):
+        def window_depth(idxs, out, prefetch_upto=0):
             """One window on the device: gather + normalise (video_depth.py:197-201), forward, resize to the source
-            size (video_depth.py:207-208) into out [32,H0,W0]."""
+            size (video_depth.py:207-208) into out [32,H0,W0]. `prefetch_upto`: frames the NEXT window will need."""
+            ensure(max(idxs) + 1)
+            compute.wait_stream(upload)
             idx = torch.tensor(idxs, dtype=torch.int32, device=dev)
             ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)
             x = xin
@@ -111,18 +128,23 @@ class VideoDepthAnything:
                 x = torch.nn.functional.interpolate(xin[0], size=(H, W), mode='bicubic', align_corners=False)[None]
             depth = eng.forward(x)                                               # [1,32,H,W] fp32
             ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)
+            ensure(prefetch_upto)                                                # overlaps this window's compute
             return out
+
+        def upto_of(k):
+            return max(plan[k]) + 1 if k < len(plan) else 0
 
         if world == 1:
             wbuf = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            windows = (window_depth(idxs, wbuf) for idxs in plan)                # lazily: stitch k queues behind forward k
+            windows = (window_depth(plan[k], wbuf, upto_of(k + 1)) for k in range(len(plan)))   # lazily: stitch k queues behind forward k
         else:
             # One process per GPU: this rank computes its block of windows with no data-path collective, ONE all-gather
             # (RCCL over xGMI) hands every rank all depth maps, and each rank stitches the whole sequence on its own GPU.
             per, order = gathered_order(len(plan), world)
             send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            for j, k in enumerate(shard_windows(len(plan), world, rank)):
-                window_depth(plan[k], send[j])
+            mine = shard_windows(len(plan), world, rank)
+            for j, k in enumerate(mine):
+                window_depth(plan[k], send[j], upto_of(k + 1) if k + 1 in mine else 0)
             recv = torch.empty(world * per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(recv, send)
             windows = (recv[i] for i in order)
