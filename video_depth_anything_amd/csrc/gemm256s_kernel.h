@@ -83,6 +83,26 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
         }
     };
 
+    // conv: (3x3 tap, 64-channel slice) of the K tile being staged. Set by tap_of() at the tile seams (one integer division by
+    // the runtime channel count), advanced incrementally inside the K loop: the division is a ~40-instruction dependent chain
+    // that would sit between the barrier and the DMA burst of every K tile.
+    int cv_tap = 0, cv_ci0 = 0;
+    auto tap_of = [&](int kt) {
+        if constexpr (AMODE == VDA_A_CONV3X3) {
+            const int k0 = kt * BK;
+            cv_tap = k0 / p.cCin;
+            cv_ci0 = k0 - cv_tap * p.cCin;
+        }
+    };
+    auto tap_next = [&]() {
+        if constexpr (AMODE == VDA_A_CONV3X3) {
+            cv_ci0 += BK;
+            if (cv_ci0 >= p.cCin) {
+                cv_ci0 = 0;
+                ++cv_tap;
+            }
+        }
+    };
     auto stage = [&](int kt, char* buf) {
         const int k0 = kt * BK;
         if constexpr (AMODE == VDA_A_DENSE) {
@@ -92,8 +112,8 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
                 glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), buf + (wave + NW * j) * 1024);
             }
         } else {
-            const int tap = k0 / p.cCin, ci0 = k0 - tap * p.cCin;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int tap = cv_tap, ci0 = cv_ci0;
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap = 0..8
 #pragma unroll
             for (int j = 0; j < AJ; ++j) {
                 const int iy = (int)(short)(a_yx[j] & 0xffff) + ky, ix = (a_yx[j] >> 16) + kx;
@@ -145,6 +165,7 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
     set_sources(tile);
+    tap_of(0);
     stage(0, smem);
     for (int round = 0; tile < ntiles; ++round) {
         const int bm = tile / nbn, bn = tile - bm * nbn;
@@ -177,7 +198,11 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
         // K tile 1 is issued after it and has the whole of K tile 0's MFMA work to land, as in the steady state.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (nt > 1) stage(1, smem + STAGE);
+        if (nt > 1) {
+            tap_of(1);
+            stage(1, smem + STAGE);
+        }
+        tap_of(2);
         read_w(smem, 0, w0);
         read_a(smem, 0, 0, a0);
         for (int kt = 0; kt < nt; ++kt) {
@@ -194,7 +219,10 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
             // are already in a1 / w1 once lgkmcnt drains): one full barrier per K tile, explicit DMA drain first.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (kt + 2 < nt) stage(kt + 2, cb);
+            if (kt + 2 < nt) {
+                stage(kt + 2, cb);
+                tap_next();
+            }
             if (kt + 1 < nt) {
                 read_w(nb, 0, w0);
                 read_a(nb, 0, 0, a0);
@@ -206,6 +234,7 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
         const int next = tile_of(round + 1);
         if (next < ntiles) {
             set_sources(next);
+            tap_of(0);
             stage(0, smem);
         }
 
