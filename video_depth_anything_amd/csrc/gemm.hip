@@ -309,7 +309,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         if (rc >= 0) {
             // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>
             static thread_local char name[64];
-            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d>", big, a.a_mode, a.epilogue);
+            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d, %d>", big, a.a_mode, a.epilogue, sched8 == 1 ? 0 : sched8 == 2 ? 2 : 1);
             else snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
             g_last_kernel = name;
             return rc;
