@@ -10,7 +10,7 @@ from video_depth_anything_amd import _lib
 for scale in (1.0, 0.3):
     q = (qkv * scale).contiguous()
     for rep in range(3):
-        for variant in (1, 2):
+        for variant in (1, 3):
             _lib.lib.vda_attention_set_variant(variant)
             for _ in range(2):
                 ops.attention(q, o, 32, 1370, H)

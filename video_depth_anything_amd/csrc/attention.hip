@@ -31,8 +31,8 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }          // 16-row conflict-free for 32-row b128 fragments
 __device__ __forceinline__ int v_swz(int row) { return ((row >> 1) & 1) << 2; }   // separates the 4 rows of a tr16 block
 
-template <bool TR, bool PK>
-__global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
+template <bool TR, bool PK, bool LSUM = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) attn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
                                                    int nqb, int total_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -84,6 +84,16 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
+    // LSUM: the softmax denominator comes out of the matrix pipe - one extra MFMA per 16-key step with an all-ones A operand
+    // sums the fp16 P the numerator uses - instead of 32 v_add_f32 per tile on the (binding) VALU.
+    f32x16 acc_l;
+    h16x8 ones;
+    if constexpr (LSUM) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_l[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ones[e] = (h16)1.f;
+    }
     constexpr float LOG2E = 1.4426950408889634f;
 
     const int nt = (N + BKV - 1) / BKV;
@@ -133,6 +143,10 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
         if (__builtin_amdgcn_readfirstlane((int)(__ballot(m_new > m_run) != 0ull))) {
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
             l_run *= alpha;
+            if constexpr (LSUM) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_l[e] *= alpha;
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -168,15 +182,16 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][e], LOG2E, -mb));
-                    ps[e & 3] += pv;
+                    if constexpr (!LSUM) ps[e & 3] += pv;
                     pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
                 }
-            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            if constexpr (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
 
         // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
 #pragma unroll
         for (int kstep = 0; kstep < 4; ++kstep) {
+            if constexpr (LSUM) acc_l = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kstep], acc_l, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 h16x8 vf;
@@ -207,7 +222,7 @@ __global__ void __launch_bounds__(256) attn_kernel(const h16* __restrict__ qkv, 
     }
 
     // ---- normalise and store: lane holds query r, channels c*32 + (e&3) + 8*(e>>2) + 4h
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = LSUM ? acc_l[0] : l_run + __shfl_xor(l_run, 32, 64);   // every row of acc_l holds the query's full sum
     const float inv = 1.0f / l_tot;
     if (q_row < N) {
         h16* op = out + ((size_t)b * N + q_row) * ((size_t)H * HD) + head * HD + 4 * h;
@@ -240,7 +255,9 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     const long long total = (long long)nqb * B * heads;
     VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (g_attn_variant == 1)
+    if (g_attn_variant == 3)
+        hipLaunchKernelGGL((attn_kernel<true, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 1)
         hipLaunchKernelGGL((attn_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant)
         hipLaunchKernelGGL((attn_kernel<true, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
