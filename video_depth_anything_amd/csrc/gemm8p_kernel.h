@@ -205,7 +205,12 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     stage_a(0, 0, smem);
     stage_a(0, 2, smem);
     stage_w(0, smem + W_BASE);
+    // In-kernel stamps (tools/gemm_stamps.py; vda_gemm_set_variant(5 + 16 * 2)): thread 0 of every workgroup writes the shader clock at
+    // tile start / K-loop start / K-loop end / tile end into the (otherwise unused) pos operand.
+    const bool stamp = EPI != VDA_EPI_PATCH_F32 && ((p.relu_in >> 9) & 1) && p.pos != nullptr && tid == 0;
+    long long* stamps = (long long*)p.pos;
     for (int round = 0; tile < ntiles; ++round) {
+        if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 0] = __builtin_readcyclecounter();
         const int bm = tile / nbn, bn = tile - bm * nbn;
         const int m0 = bm * BM, n0 = bn * BN;
 
@@ -253,6 +258,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();                                  // ... and everyone's
+        if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 1] = __builtin_readcyclecounter();
         if (wm == 1) bar();                     // waves 4..7 run one barrier behind from here to the end of the K loop
 
         int sa = 0;                             // A slot of K tile kt (kt % 3)
@@ -352,6 +358,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             sa = sa == 2 ? 0 : sa + 1;
         }
         if (wm == 0) bar();                     // re-align the two groups: every wave is past its last MFMA section's reads
+        if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 2] = __builtin_readcyclecounter();
         // Nobody reads the pipeline buffers any more. The NEXT tile's first K tile is issued after the first 32-row block of
         // the epilogue (below): early enough that the rest of the epilogue covers its HBM/L2 latency, late enough that the
         // epilogue's own first loads (column constants, residual rows) do not queue behind it on the in-order vmcnt.
@@ -452,7 +459,11 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 if (interior) row_groups(std::false_type{});
                 else row_groups(std::true_type{});
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
-                if (i == 0 && next < ntiles && !(dbg & 1)) {
+                // Epilogues with row-dependent loads (residual, pos-embed) prefetch after their LAST block instead: with an LDS-DMA
+                // in flight hipcc waits vmcnt(0) - every store included - at each of those loads (dbg bit 2 switches this off)
+                constexpr bool ROW_AUX = EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H || EPI == VDA_EPI_RES_F16 || EPI == VDA_EPI_PATCH_F32;
+                const int pf_block = (ROW_AUX && !(dbg & 4)) ? MI / 2 - 1 : 0;
+                if (i == pf_block && next < ntiles && !(dbg & 1)) {
                     load_bias(next);
                     set_sources(next);
                     tap_of(0);
@@ -466,6 +477,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         // barrier (a __syncthreads here would also drain the stores and the prefetched K tile 0).
         lgkm0();
         bar();
+        if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 3] = __builtin_readcyclecounter();
         tile = next;
     }
 }
