@@ -203,3 +203,20 @@ def test_full_size_vitl_properties():
     # temporal attention, so instead check the B axis: a batch of the same clip twice gives identical halves.
     d3 = m(torch.cat([x[:, :8], x[:, :8]], dim=0).contiguous())
     assert torch.equal(d3[0], d3[1])
+
+
+def test_two_ranks_share_one_gpu(tmp_path):
+    """The multi-rank branch of infer_video_depth rehearsed with 2 processes on this one GPU (gloo stands in for RCCL; the
+    exchange is staged through the host): both ranks must return exactly what a single rank returns."""
+    import subprocess
+    import sys
+    out = tmp_path / "r"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(REPO, "tests", "_gpu_ranks_worker.py"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    single = np.load(f"{out}_single.npy")
+    for rank in (0, 1):
+        d = np.load(f"{out}_rank{rank}.npy")
+        assert d.shape == single.shape == (60, 28, 42)
+        assert np.array_equal(d, single), f"rank {rank} differs from the single-rank result"

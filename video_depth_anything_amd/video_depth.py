@@ -17,6 +17,18 @@ from .scheduler import network_size
 _FP32_WARNED = False
 
 
+def _all_gather(out, inp):
+    """out[r] = rank r's `inp`. NCCL (= RCCL): asynchronous on the collective's own stream, returns the work handle.
+    Any other backend (gloo: the 2-ranks-on-one-GPU rehearsal of tests/test_forward_gpu.py) is staged through the host."""
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(out, inp, async_op=True)
+    parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, inp.cpu())
+    out.copy_(torch.stack(parts))
+    return None
+
+
 class VideoDepthAnything:
     METRIC = False   # metric variant stitches with scale=1, shift=0 (metric_depth/.../video_depth.py:132)
 
@@ -138,16 +150,24 @@ class VideoDepthAnything:
             wbuf = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
             windows = (window_depth(plan[k], wbuf, upto_of(k + 1)) for k in range(len(plan)))   # lazily: stitch k queues behind forward k
         else:
-            # One process per GPU: this rank computes its block of windows with no data-path collective, ONE all-gather
-            # (RCCL over xGMI) hands every rank all depth maps, and each rank stitches the whole sequence on its own GPU.
-            per, order = gathered_order(len(plan), world)
-            send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            # One process per GPU: this rank computes its block of windows with no data-path collective; each finished window
+            # is all-gathered (RCCL over xGMI; asynchronously, under the next window's compute) so that every rank ends up
+            # with all depth maps and stitches the whole sequence on its own GPU. Ranks with one window fewer send a zero slot.
+            per, _ = gathered_order(len(plan), world)
             mine = shard_windows(len(plan), world, rank)
-            for j, k in enumerate(mine):
-                window_depth(plan[k], send[j], upto_of(k + 1) if k + 1 in mine else 0)
-            recv = torch.empty(world * per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(recv, send)
-            windows = (recv[i] for i in order)
+            send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            recv = torch.empty(per, world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
+            pending = []
+            for j in range(per):
+                if j < len(mine):
+                    k = mine[j]
+                    window_depth(plan[k], send[j], upto_of(k + 1) if j + 1 < len(mine) else 0)
+                pending.append(_all_gather(recv[j], send[j]))
+            for h in pending:
+                if h is not None:
+                    h.wait()
+            counts = [len(shard_windows(len(plan), world, r)) for r in range(world)]
+            windows = (recv[j, r] for r in range(world) for j in range(counts[r]))     # window order = rank-major blocks
         depths = stitch_stream(windows, n, H0, W0, dev, metric=self.METRIC)
         return depths, target_fps
 
