@@ -221,21 +221,19 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             for (int j = 0; j < NJ; ++j) acc[i][j] = nbias[j];
         // ReLU on the conv activation operand: in the LOAD section (after the fragments landed, before the barrier), so it
         // runs under the partner wave's MFMA section instead of delaying this wave's
-        auto relu_a = [&](AF& fa) {
-            if constexpr (AMODE == VDA_A_CONV3X3) {
-#pragma unroll
-                for (int i = 0; i < MH; ++i) fa.a[i] = __builtin_elementwise_max(fa.a[i], relu_thr);
-            }
-        };
+        auto relu_a = [&](AF&) {};               // (the ReLU now rides inside the MFMA cluster, see mma)
         auto mma = [&](int half, AF& fa, const WF& fw) {
             if constexpr (SCHED != 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < MH; ++i)
+            for (int i = 0; i < MH; ++i) {
+                // conv ReLU on the activation fragment just before its 4 MFMAs: 4 packed max per fragment ride in the MFMA gaps
+                if constexpr (AMODE == VDA_A_CONV3X3) fa.a[i] = __builtin_elementwise_max(fa.a[i], relu_thr);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     if (half == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[i][j], 0, 0, 0);
                     else acc[MH + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw.w[j], fa.a[i], acc[MH + i][j], 0, 0, 0);
                 }
+            }
             if constexpr (SCHED != 2) __builtin_amdgcn_s_setprio(0);
         };
 
