@@ -6,8 +6,8 @@
 //
 //   workgroup = 8 x 32 output pixels, 4 waves; a wave owns 2 output rows = two 32-pixel MFMA column blocks
 //   pass      = 32 input channels: LDS holds the patch [340 pixels][32 ch] and the weights [9 taps x 32 cout][32 ch]
-//               (64-byte rows; 16-byte chunks XOR-swizzled by (row >> 1) & 3: any 16 consecutive rows of one chunk
-//               cover the eight 16-byte bank groups exactly twice = conflict-free ds_read_b128). 40 KiB -> 3 workgroups
+//               (64-byte rows; 16-byte chunks XOR-swizzled by (row >> 2) & 3: any 16 consecutive rows of one chunk
+//               cover the sixteen 16-byte slots of a bank row = conflict-free ds_read_b128). 40 KiB -> 3 workgroups
 //               per CU, so one workgroup's fill overlaps its neighbours' MFMA phase.
 //   weights   : LDS-DMA per pass (L2 -> LDS, 18 KiB). Re-reading them from L2 per MFMA made v1 L2-bandwidth-bound.
 //   patch fill: SRC_UP = 0: 16-byte LDS-DMA straight from the tensor (zero page outside the image = conv padding)
@@ -38,7 +38,10 @@ constexpr int NK = (NPIX + 63) / 64;           // bilinear items per thread and 
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ int swz(int r) { return (r >> 1) & 3; }
+// ds_read_b128 is served 16 lanes at a time against one 256-byte bank row = sixteen 16-byte slots. Row r of 64 bytes puts chunk c
+// at slot 4 * (r & 3) + c: 16 consecutive rows of one chunk must hit 16 different slots, so rows r, r+4, r+8, r+12 need 4 different
+// chunk positions -> XOR with (r >> 2) & 3. (The first version used (r >> 1) & 3: 8 slots hit twice, 44 % conflict cycles measured.)
+__device__ __forceinline__ int swz(int r) { return (r >> 2) & 3; }
 
 // a + (b - a) * w on 8 halfs as four v_pk_add_f16 + four v_pk_fma_f16 (w = one VGPR holding the weight twice)
 __device__ __forceinline__ h16x8 lerp8(const h16x8 a, const h16x8 b, const h16x2 w) {
