@@ -117,11 +117,12 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // ---- MFMA form: one wave per (pixel, head), 4 heads per workgroup, no cross-wave traffic (each wave stages, computes and
 // stores its own head, so LDS ordering is the wave's own lgkmcnt).
-//   LDS per wave: q (later v) and k as [32 frames][D channels] fp16 rows of 2D + 32 bytes (the 32-byte pad shifts consecutive rows by 8
-//   banks: conflict-free for the 32-row ds_read_b128 fragments and for the 4-row ds_read_b64_tr_b16 blocks).
+//   LDS per wave: q (later v) and k as [32 frames][D channels] fp16 rows of 2D + 48 (80 at D = 64) bytes, see RSB.
 template <int D>
 __global__ void __launch_bounds__(256) tattn_mfma_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int T, int hw, int C, int heads) {
-    constexpr int RSB = 2 * D + 32;                           // row bytes
+    constexpr int RSB = 2 * D + (D == 64 ? 80 : 48);          // row bytes: an ODD number of 16-byte slots (16 consecutive rows of one column hit
+                                                              // 16 different slots of the 256-byte bank row: conflict-free ds_read_b128) whose multiples
+                                                              // 0..3 stay >= 32 bytes apart mod 256 (the 4-row ds_read_b64_tr_b16 blocks)
     constexpr int TEN = TMAX * RSB;                          // one tensor of one head
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
     const int lane = threadIdx.x & 63;
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256) tattn_mfma_kernel(const h16* __restrict__
 
 template <int D>
 int launch_tattn_mfma(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipStream_t s) {
-    constexpr size_t smem = (size_t)4 * 2 * TMAX * (2 * D + 32);
+    constexpr size_t smem = (size_t)4 * 2 * TMAX * (2 * D + (D == 64 ? 80 : 48));
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
