@@ -14,7 +14,9 @@ Harness shims (none of them replaces arithmetic on the pinned path):
 the object is assembled as `pretrained = DINOv2(encoder)`, `head = DPTHeadTemporal(...)`,
 which is what the commented upstream constructor at :59 and metric_depth/...:54 do.
 
-Usage:  python oracle/gen_golden.py [--metric]
+Usage:  python oracle/gen_golden.py [--metric] [--check]
+  --check   regenerate into a temporary directory and assert that every array equals the committed fixture bit for bit
+            (tests/test_oracle_golden.py runs this when /root/reference is present).
 """
 import argparse
 import os
@@ -69,6 +71,10 @@ def install_shims():
 
 def build_reference(cfg, sd, ref_root):
     sys.path.insert(0, ref_root)
+    # `utils` must resolve to the reference's namespace package (utils/util.py), not to this repo's utils/ directory:
+    # drop anything cached under that name and let the import system merge the two directories (neither has __init__.py).
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
     import torch.nn as nn
     from video_depth_anything import video_depth as vd
     from video_depth_anything.dinov2 import DINOv2, DinoVisionTransformer
@@ -116,10 +122,32 @@ def capture_stages(model):
     return store, hs
 
 
+def compare_dirs(fresh, committed):
+    """Every array of every freshly generated fixture must equal the committed one exactly."""
+    bad = []
+    for name in sorted(os.listdir(fresh)):
+        a, b = np.load(os.path.join(fresh, name)), np.load(os.path.join(committed, name))
+        if sorted(a.files) != sorted(b.files):
+            bad.append(f"{name}: keys differ")
+            continue
+        for k in a.files:
+            if a[k].shape != b[k].shape or a[k].dtype != b[k].dtype or not np.array_equal(a[k], b[k]):
+                bad.append(f"{name}:{k}")
+    if bad:
+        raise SystemExit("golden fixtures differ from a fresh run of the reference: " + ", ".join(bad))
+    print("check ok:", ", ".join(sorted(os.listdir(fresh))), "are bit-identical to tests/golden")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--metric", action="store_true", help="generate the metric_depth stitch golden instead")
+    ap.add_argument("--check", action="store_true", help="regenerate to a temp dir and compare with tests/golden bit for bit")
     args = ap.parse_args()
+    global OUT
+    committed = OUT
+    if args.check:
+        import tempfile
+        OUT = tempfile.mkdtemp(prefix="vda_golden_")
     install_shims()
     from video_depth_anything_amd.config import get_config
     from video_depth_anything_amd.weights import synthetic_state_dict
@@ -138,6 +166,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "tiny_metric_video.npz"), frames=frames, depths=depths.astype(np.float32),
                             sd_seed=6, sd_checksum=sd_checksum(sd), input_size=42)
         print("tiny_metric_video", depths.shape, float(depths.mean()))
+        if args.check:
+            compare_dirs(OUT, committed)
         return
 
     # ---- 1. tiny config, non-square input, every stage tapped --------------------
@@ -208,6 +238,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "stitch_math.npz"), pred=pred, targ=targ, scale=np.float64(s), shift=np.float64(t),
                         pre=np.stack(pre), post=np.stack(post), mix=np.stack(mix))
     print("stitch_math", s, t)
+    if args.check:
+        compare_dirs(OUT, committed)
 
 
 if __name__ == "__main__":

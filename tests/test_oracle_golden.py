@@ -89,3 +89,18 @@ def test_window_plan_counts():
     assert O.window_plan(32) == (22, [0, 22])
     a, s = O.window_plan(1024)
     assert (a, len(s)) == (20, 47)
+
+
+@pytest.mark.parametrize("flags", [[], ["--metric"]], ids=["relative", "metric"])
+def test_golden_recipe_reproduces_the_committed_fixtures(flags):
+    """The pin is only as good as its recipe: oracle/gen_golden.py must still run against the reference and reproduce
+    tests/golden bit for bit. Needs /root/reference (build container only; the GPU box has no reference)."""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/video_depth_anything"):
+        pytest.skip("/root/reference is not present on this machine")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "oracle", "gen_golden.py"), "--check"] + flags,
+                       capture_output=True, text=True, timeout=600, cwd=repo)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "check ok" in r.stdout
