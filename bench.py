@@ -29,21 +29,57 @@ CLIP_TFLOP = {"vitl": 44.95, "vits": 3.881}
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense fp16/bf16 (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(encoder, frames=2):
-    """Oracle on the host cores: same weights/shape per frame, `frames` of the clip's 32 frames."""
+def physical_cores():
+    """(physical cores, CPU model) of the host: torch's default thread count is the LOGICAL count, which oversubscribes
+    the FMA units of an SMT machine (round 1: 128 threads ran slower than 8 threads in the build container)."""
+    model, pairs, phys, core = "unknown", set(), None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                pairs.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    n = len(pairs) or max(1, (os.cpu_count() or 2) // 2)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return n, model
+
+
+def cpu_baseline(encoder, full=False):
+    """The CPU oracle (the checker, kind = "port") on the bench's own x = randn(1,32,3,518,518) and weights, on the host's
+    physical cores. ViT-S: the whole 32-frame clip, 1 warm-up + 3 reps. ViT-L: a bounded sample - the first 4 frames of x at the
+    full 518x518 (per-frame cost is what the sample must preserve: encoder and head FLOPs are per frame, temporal attention
+    is 0.07 % of the clip) after a 1-frame warm-up; --cpu-full times the whole 32-frame clip instead (minutes)."""
     from oracle import vda_oracle as O
     from video_depth_anything_amd.config import get_config
     from video_depth_anything_amd.weights import synthetic_state_dict
     cfg = get_config(encoder)
     sd = synthetic_state_dict(cfg, seed=0)
-    x = torch.randn(1, frames, 3, 518, 518, generator=torch.Generator().manual_seed(0))
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
+    cores, cpu = physical_cores()
+    torch.set_num_threads(cores)
+    x = torch.randn(1, 32, 3, 518, 518, generator=torch.Generator().manual_seed(0))
+    frames, reps = (32, 3) if encoder == "vits" else ((32, 1) if full else (4, 1))
     with torch.no_grad():
-        O.forward(sd, cfg, x)
-    dt = time.perf_counter() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{encoder} fp32 torch-CPU oracle, 1x{frames}x518x518 ({frames} of the clip's 32 frames), 1 rep, {dt:.1f} s"}
+        O.forward(sd, cfg, x[:, :1] if encoder == "vitl" else x[:, :frames])          # warm-up
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.forward(sd, cfg, x[:, :frames])
+        dt = (time.perf_counter() - t0) / reps
+    return {"value": frames / dt, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu,
+            "sample": f"{encoder} fp32 torch-CPU oracle on x[:, :{frames}] of the bench's randn(1,32,3,518,518) "
+                      f"({'the whole clip' if frames == 32 else f'{frames} of its 32 frames at full 518x518'}), 1 warm-up + {reps} rep(s), "
+                      f"{dt:.1f} s per rep, {cores} threads = physical cores"}
 
 
 def main():
@@ -53,6 +89,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--encoder", default="vitl", choices=["vitl", "vits"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="time the CPU oracle on the whole 32-frame clip (ViT-L: minutes)")
+    ap.add_argument("--fp32", action="store_true", help="bench the fp32-operand path (the reference's --fp32) instead of the headline fp16 path")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -75,7 +113,6 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from video_depth_anything_amd import ops
     from video_depth_anything_amd.config import get_config
     from video_depth_anything_amd.video_depth import VideoDepthAnything
     from video_depth_anything_amd.weights import synthetic_state_dict
@@ -87,8 +124,9 @@ def main():
     T, H, W = 32, 518, 518
     x = torch.randn(1, T, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)   # resident in HBM
 
+    fwd = lambda: model.forward(x, fp32=args.fp32)          # explicit precision: a bare model(x) follows torch.autocast
     for _ in range(args.warmup):
-        model(x)
+        fwd()
     outs = torch.empty(args.steps, T, H, W, dtype=torch.float32, device=dev)
     gathered = torch.empty(args.steps, world, T, H, W, dtype=torch.float32, device=dev) if world > 1 else None
 
@@ -101,14 +139,14 @@ def main():
         dist.all_gather(parts, outs[s].cpu())
         gathered[s].copy_(torch.stack(parts))
         return None
-    ops.PROFILE = ops.GemmProfile(every=4)
+    model.engine.profile_start(every=4)       # 1 in 4 GEMM / conv launches of each shape bracketed by HIP events on the launch stream
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pending = []
     for s in range(args.steps):
-        outs[s].copy_(model(x)[0])
+        outs[s].copy_(fwd()[0])
         if dist is not None:
             pending.append(exchange(s))
     if dist is not None:
@@ -118,7 +156,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    prof = model.engine.profile_stop()          # {kernel: launches, flops, timed, timed_ms, timed_flops}
 
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -128,43 +166,45 @@ def main():
     if rank == 0:
         # ---- dominant kernel: per-launch durations from the events recorded in the timed region
         # (1 launch in 4 of each shape is bracketed; totals = sampled rate x all launches' algorithmic flops)
-        agg = {}
-        for name, flops, e0, e1 in prof.samples:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += flops
-        est = {k: prof.launches[k][1] / (v[2] / v[1]) for k, v in agg.items()}      # estimated seconds in the timed region
+        agg = {k: [v["timed"], v["timed_ms"] * 1e-3, v["timed_flops"]] for k, v in prof.items() if v["timed"] > 0}
+        launches = {k: (v["launches"], v["flops"]) for k, v in prof.items()}
+        est = {k: launches[k][1] / (v[2] / v[1]) for k, v in agg.items()}      # estimated seconds in the timed region
         dom = max(est, key=est.get)
         sampled, secs, flops = agg[dom]
-        calls = prof.launches[dom][0]
+        calls = launches[dom][0]
         # HBM bytes per launch of that kernel: cannot be read live (needs rocprofv3 --pmc passes); taken from the
         # committed PMC summary of the same command (tools/pmc_bench.sh -> profiles/), null when absent.
         traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", f"{args.encoder}_pmc_hbm_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, f"{args.encoder}_pmc_hbm_traffic.json")
+            if os.path.exists(pmc) and not args.fp32:
+                traffic = json.load(open(pmc))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    break
         achieved = flops / secs / 1e12
         fps = world * args.steps * T / dt
+        peak = 157.3 if args.fp32 else MFMA_PEAK_TFLOPS          # fp32-input MFMA runs at 1/16 of the fp16 rate (MI355X_MICROARCH.md)
+        prec = "fp32" if args.fp32 else "fp16"
         line = {
-            "metric": "frames/sec at 1x32x518x518 fp16, ViT-L" if args.encoder == "vitl" else "frames/sec at 1x32x518x518 fp16, ViT-S",
+            "metric": f"frames/sec at 1x32x518x518 {prec}, ViT-L" if args.encoder == "vitl" else f"frames/sec at 1x32x518x518 {prec}, ViT-S",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.encoder} fp16 32-frame clip forward, x=randn(1,32,3,518,518), seeded random weights "
+            "dtype": "f32" if args.fp32 else "f16", "data": "synthetic",
+            "config": {"workload": f"{args.encoder} {prec} 32-frame clip forward, x=randn(1,32,3,518,518), seeded random weights "
                                    f"(BASELINE.json configs[{2 if args.encoder == 'vitl' else 1}])",
-                       "clips_per_step_per_gpu": 1, "parallelism": f"independent windows x{world}" + (", per-step all-gather of depth overlapped with compute" if world > 1 else "")},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "launches": calls,
+                       "clips_per_step_per_gpu": 1, "parallelism": f"independent windows x{world}" + (", per-step all-gather of depth overlapped with compute" if world > 1 else ""),
+                       "world": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "launches": calls,
                          "launches_timed": sampled, "avg_launch_us": secs / sampled * 1e6,
                          "algorithmic_gflop_per_launch": flops / sampled / 1e9, "share_of_step_time": est[dom] / dt},
             "model_tflops": CLIP_TFLOP[args.encoder] * world * args.steps / dt,
-            "model_mfma_frac": CLIP_TFLOP[args.encoder] * world * args.steps / dt / (MFMA_PEAK_TFLOPS * world),
-            "kernels": {k: {"launches": prof.launches[k][0], "launches_timed": v[0], "ms_per_step": est[k] / args.steps * 1e3,
+            "model_mfma_frac": CLIP_TFLOP[args.encoder] * world * args.steps / dt / (peak * world),
+            "kernels": {k: {"launches": launches[k][0], "launches_timed": v[0], "ms_per_step": est[k] / args.steps * 1e3,
                             "tflops": v[2] / v[1] / 1e12} for k, v in agg.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.encoder)
+            line["cpu_baseline"] = cpu_baseline(args.encoder, full=args.cpu_full)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

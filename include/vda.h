@@ -13,9 +13,11 @@
  *  - every function enqueues on `stream` (a hipStream_t passed as void*) and
  *    returns immediately: 0 = ok, non-zero = refused (bad shape/alignment; the
  *    text is available from vda_last_error()); nothing is launched on refusal;
- *  - activations are fp16 ("h"), token-major / NHWC; accumulation is fp32;
- *  - not thread-safe per stream; no allocation, no synchronisation inside
- *    (graph-capturable).
+ *  - activations are token-major / NHWC; the *_f16 entry points take fp16 ("h") activations and fp16 MFMA operands with
+ *    fp32 accumulation (the reference's autocast path, video_depth.py:203-205 with fp32=False); the *_f32 twins take
+ *    fp32 activations and fp32 MFMA operands (exact fp32 products: the reference's fp32=True path, run.py:31);
+ *  - the per-kernel entry points are not thread-safe per stream and do no allocation or synchronisation inside
+ *    (graph-capturable); the handle API at the end of this file owns memory and says where it allocates.
  */
 #ifndef VDA_H
 #define VDA_H
@@ -76,6 +78,9 @@ typedef struct vda_gemm_args {
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
+/* fp32-operand twin (v_mfma_f32_32x32x2_f32, exact fp32): A, W, res, res2 and out are fp32; K % 16 == 0, conv Cin % 16 == 0.
+ * The epilogue ids keep their meaning (what is fused); every "_F16" output / residual is fp32 here. */
+int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
 /* Tuning hook: -1 (default) picks the tile per shape; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 tiles on
  * 32x32x16 MFMA; 3 / 4 = the same tiles on 16x16x32 MFMA (what -1 uses for wide N). */
 int vda_gemm_set_variant(int v);
@@ -94,9 +99,16 @@ int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const floa
                           int rows, int D, int group, int skip,
                           const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream);
 
+/* fp32-operand path: same, fp32 out. */
+int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const float* b, float eps,
+                          int rows, int D, int group, int skip,
+                          const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream);
+
 /* GroupNorm(32 groups) per frame on NHWC fp16 [frames, hw, C] -> fp16 [frames*hw, C]
  * (motion_module.py:84,110). `partial` is workspace of frames*chunks*groups*2 floats. */
 int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps,
+                           int frames, int hw, int C, int groups, float* partial, int chunks, vda_stream_t stream);
+int vda_groupnorm_nhwc_f32(const float* in, float* out, const float* w, const float* b, float eps,
                            int frames, int hw, int C, int groups, float* partial, int chunks, vda_stream_t stream);
 
 /* ---------------------------------------------------------------- attention
@@ -104,6 +116,8 @@ int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const floa
  * call at :76): qkv fp16 [B, N, 3, heads, 64] -> out fp16 [B, N, heads*64],
  * softmax(q k^T / 8) v with fp32 softmax, never materialising the N x N scores. */
 int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream);
+/* fp32-operand twin: qkv fp32 [B, N, 3, heads, 64] -> out fp32 [B, N, heads*64], every product on fp32 MFMA. */
+int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda_stream_t stream);
 /* Debug cross-check: 1 (default) = V^T fragments via ds_read_b64_tr_b16, 0 = scalar LDS reads. */
 int vda_attention_set_variant(int v);
 
@@ -111,6 +125,7 @@ int vda_attention_set_variant(int v);
  * motion_module/attention.py:182-211): qkv fp16 [T*hw, 3*C] frame-major rows,
  * 8 heads of d = C/8 -> out fp16 [T*hw, C]. Batch b>1 is expressed by calling per clip. */
 int vda_temporal_attention_f16(const void* qkv, void* out, int T, int hw, int C, int heads, vda_stream_t stream);
+int vda_temporal_attention_f32(const float* qkv, float* out, int T, int hw, int C, int heads, vda_stream_t stream);
 /* 1 (default): MFMA kernel for head dims 32 / 64 / 128, VALU kernel otherwise; 0: VALU kernel everywhere (cross-check). */
 int vda_temporal_attention_set_variant(int v);
 
@@ -120,12 +135,20 @@ int vda_temporal_attention_set_variant(int v);
  * (same shape as out). */
 int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add, int B, int h, int w, int H, int W, int C,
                           vda_stream_t stream);
+int vda_bilinear_nhwc_f32(const float* in, float* out, const float* add, int B, int h, int w, int H, int W, int C,
+                          vda_stream_t stream);
 /* fp32 planes [B,h,w] -> [B,H,W], optional relu (video_depth.py:162-163,208). */
 int vda_bilinear_plane_f32(const float* in, float* out, int B, int h, int w, int H, int W, int relu, vda_stream_t stream);
 
 /* Patch gather for the 14x14/s14 patch-embed conv (patch_embed.py:76): fp32 NCHW
  * [B,3,H,W] -> fp16 [B*(H/14)*(W/14), Kpad], column = c*196 + ky*14 + kx, zero padded to Kpad. */
 int vda_patchify_f32_f16(const float* x, void* out, int B, int H, int W, int Kpad, vda_stream_t stream);
+int vda_patchify_f32_f32(const float* x, float* out, int B, int H, int W, int Kpad, vda_stream_t stream);
+
+/* Positional-embedding grid for a (ph x pw)-patch input (dinov2.py:185-210): pe fp32 [1 + g*g, D] -> out fp32 [1 + ph*pw, D];
+ * row 0 (cls) is copied, the g x g grid is resampled bicubic (a = -0.75, half-pixel centres, clamped taps) with the
+ * reference's explicit scale factors ((ph + 0.1)/g, (pw + 0.1)/g). Not needed when ph*pw == g*g and the input is square. */
+int vda_pos_embed_resample_f32(const float* pe, float* out, int g, int ph, int pw, int D, vda_stream_t stream);
 
 /* cls rows of the token matrix: tok[b*(P+1), :] = cls + pos[0] (dinov2.py:218-219). */
 int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int P, int D, vda_stream_t stream);
@@ -133,6 +156,7 @@ int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int 
 /* Final 1x1 conv 32->1 + ReLU on NHWC fp16 [rows, Cpad] (first 32 channels used)
  * -> fp32 [rows] (dpt.py:121-122). */
 int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream);
+int vda_head_out_f32_f32(const float* in, const float* w, float bias, float* out, long long rows, int Cpad, vda_stream_t stream);
 
 /* Fused depth tail (dpt.py:118-122, dpt_temporal.py:93-100, video_depth.py:162-163): NHWC fp16 [B,h,w,C] ->
  * [bilinear align_corners resize to H x W when (h,w) != (H,W)] -> 3x3 conv C->32 (+b2, ReLU) -> 1x1 conv 32->1 (+b3, ReLU)
@@ -148,6 +172,14 @@ int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W,
 int vda_gather_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H, int W,
                                 vda_stream_t stream);
 
+/* Window gather + resize to the network size + normalise, for source frames that are not already H x W (the usual case for
+ * real video, util/transform.py:109-147): out[i] = normalise(bicubic(video[idx[i]] / 255)), uint8 [n_video,H0,W0,3] ->
+ * fp32 NCHW [n,3,H,W]. Bicubic as cv2.INTER_CUBIC defines it: a = -0.75, half-pixel centres, taps clamped to the border,
+ * no antialiasing. (cv2 is absent offline: parity of this leg against cv2 itself is unpinned; it is tested against the
+ * same definition evaluated by torch on the CPU.) */
+int vda_gather_resize_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H0, int W0,
+                                       int H, int W, vda_stream_t stream);
+
 /* ---- window stitcher on the device (video_depth.py:216-254) ------------------------------------------------
  * Least-squares scale / shift of `pred` against `target` over all n pixels (utils/util.py:40-62 with the all-ones
  * mask of video_depth.py:232): scale_shift[0..1] (device) = closed form on fp64 sums, (1, 0) when det == 0.
@@ -160,6 +192,66 @@ int vda_lsq_scale_shift_f32(const float* pred, const float* target, long long n,
  * chunk: fp32 [22, px]; tail: fp32 [8, px] updated in place; scale_shift, wts: device fp32 [2], [16]. */
 int vda_stitch_window_f32(const float* win, const float* scale_shift, float* chunk, float* tail, float* ref1, long long px,
                           const float* wts, vda_stream_t stream);
+
+/* ================================================================ handle API: the model behind one pointer
+ * What a C / C++ host binds in place of the reference's Python class (the seam of SURVEY.md section 8b):
+ *   VideoDepthAnything(**model_configs[enc])          run.py:45, video_depth.py:38-63      vda_create
+ *   .load_state_dict(torch.load(ckpt), strict=True)   run.py:46                            vda_load_weight per tensor, then
+ *                                                                                          vda_finalize_weights
+ *   .to('cuda')                                       run.py:47                            (the handle lives on the device
+ *                                                                                           that is current at vda_create)
+ *   model.forward(x)                                  video_depth.py:89-93,161-164         vda_forward
+ * Ownership: the caller owns `in`, `out` and (optionally) the workspace block; the handle owns its weights and frees them
+ * in vda_destroy. Errors: non-zero return, text from vda_last_error() - for state-dict problems in torch's own wording
+ * ("Missing key(s) in state_dict: ...", "Unexpected key(s) ...", "size mismatch for ..."). A handle is not thread-safe and
+ * is bound to one device: every call must be made with that device current.
+ * Allocation / synchronisation: vda_load_weight copies synchronously (host or device source); vda_finalize_weights packs
+ * the fp16 layouts on the device and synchronises; the FIRST vda_forward of a new (shape, precision) - or vda_prepare -
+ * may allocate (the fp32 weight pack, the positional embedding at that grid, the handle's own workspace when the caller
+ * gave none). After that vda_forward only enqueues kernels on `stream`. */
+typedef struct vda_model vda_model;
+
+typedef struct vda_config {
+    int32_t embed_dim;        /* 384 (vits) / 1024 (vitl); num_heads * 64                  dinov2.py:339-378 */
+    int32_t depth;            /* 12 / 24 transformer blocks */
+    int32_t num_heads;        /* 6 / 16 */
+    int32_t taps[4];          /* blocks whose output feeds the head: 2,5,8,11 / 4,11,17,23   video_depth.py:53-56 */
+    int32_t features;         /* 64 / 256                                                    run.py:41-42 */
+    int32_t out_channels[4];  /* 48,96,192,384 / 256,512,1024,1024 */
+    int32_t num_frames;       /* 32: temporal window (pos_encoder.pe rows) */
+} vda_config;
+
+enum vda_precision {
+    VDA_PREC_F16 = 0,         /* fp16 MFMA operands, fp32 accumulate / residual streams / norm + softmax statistics */
+    VDA_PREC_F32 = 1          /* fp32 operands everywhere (exact-fp32 MFMA): the reference's fp32=True */
+};
+enum vda_dtype { VDA_DTYPE_F32 = 0 };
+
+int vda_create(const vda_config* cfg, vda_model** out);
+int vda_destroy(vda_model* h);
+/* Number of tensors the state dict must hold (351 for vits, 519 for vitl). */
+int vda_num_weights(const vda_model* h);
+/* One tensor of the flat fp32 state dict, under the reference's key (e.g. "pretrained.blocks.0.attn.qkv.weight"); `ptr` is
+ * host or device memory and is copied. Unknown keys and shape mismatches are refused. */
+int vda_load_weight(vda_model* h, const char* name, const void* ptr, const int64_t* dims, int ndim, int dtype);
+/* strict=True check (every key present) + repack to the kernel layouts. */
+int vda_finalize_weights(vda_model* h);
+/* Bytes of workspace a forward of x[B,T,3,H,W] needs at this precision (-1 on error). */
+int64_t vda_workspace_bytes(vda_model* h, int B, int T, int H, int W, int precision);
+/* Optional: run in a caller-owned, 256-byte aligned block (e.g. a torch tensor) instead of one the handle allocates. */
+int vda_set_workspace(vda_model* h, void* ptr, int64_t bytes);
+/* Optional: do now whatever the first forward of this shape / precision would allocate. */
+int vda_prepare(vda_model* h, int B, int T, int H, int W, int precision);
+/* in: fp32 device [B,T,3,H,W] (normalised frames; H, W multiples of 14; T <= num_frames) -> out: fp32 device [B,T,H,W]. */
+int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream);
+/* Parity hook: copy `bytes` of a named intermediate of the last forward ("tap0".."tap3", "l1", "l2", "l3t", "l4t", "p4t",
+ * "p3t", "p2", "p1"; activation dtype of that forward's precision, channels padded to multiples of 64) to device `dst`. */
+int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream);
+/* Measurement hook (bench.py): from vda_profile_start until vda_profile_stop every `every`-th GEMM / conv launch of each
+ * (shape, epilogue) inside vda_forward is bracketed by two events on the launch stream. vda_profile_stop waits for them and
+ * writes a JSON object {kernel: {"launches", "flops", "timed", "timed_ms", "timed_flops"}} into json[cap]. */
+int vda_profile_start(vda_model* h, int every);
+int vda_profile_stop(vda_model* h, char* json, int cap);
 
 #ifdef __cplusplus
 }

@@ -14,11 +14,11 @@ from video_depth_anything_amd.weights import synthetic_state_dict  # noqa: E402
 
 
 def main():
-    out = sys.argv[1]
+    out, n_frames = sys.argv[1], int(sys.argv[2])
     torch.set_num_threads(2)
     cfg = get_config("tiny")
     sd = synthetic_state_dict(cfg, seed=5)
-    frames = np.random.default_rng(21).integers(0, 256, (60, 28, 42, 3), dtype=np.uint8)   # 3 windows: ranks get 2 + 1
+    frames = np.random.default_rng(21).integers(0, 256, (n_frames, 28, 42, 3), dtype=np.uint8)   # 60 -> 3 windows, 100 -> 5
     calls = []
 
     def window_fn(win_u8):
@@ -30,7 +30,8 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     d = S.run_windows(frames, window_fn)
-    assert len(calls) == len(S.shard_windows(3, 2, rank)), "each rank computes only its own windows"
+    nwin = len(S.plan_windows(n_frames))
+    assert len(calls) == len(S.shard_windows(nwin, dist.get_world_size(), rank)), "each rank computes only its own windows"
     np.save(f"{out}_rank{rank}.npy", d)
     dist.barrier()
     dist.destroy_process_group()

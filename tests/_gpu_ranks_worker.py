@@ -1,5 +1,5 @@
-"""Worker for test_two_ranks_share_one_gpu (launched by torch.distributed.run, backend gloo, both ranks on cuda:0):
-the multi-rank branch of infer_video_depth - sharding, padded slots, gather order, device stitch - against one rank."""
+"""Worker for test_ranks_share_one_gpu (launched by torch.distributed.run, backend gloo, all ranks on cuda:0):
+the multi-rank branch of infer_video_depth - round-robin shards, per-round exchange, two-slot rings, device stitch - against one rank."""
 import os
 import sys
 
@@ -19,14 +19,21 @@ def main():
     m = VideoDepthAnything(encoder="tiny", features=cfg.features, out_channels=list(cfg.out_channels))
     m.load_state_dict(synthetic_state_dict(cfg, seed=5), strict=True)
     m = m.to("cuda").eval()
-    frames = np.random.default_rng(21).integers(0, 256, (60, 28, 42, 3), dtype=np.uint8)   # 3 windows: ranks get 2 + 1
+    frames = np.random.default_rng(21).integers(0, 256, (100, 28, 42, 3), dtype=np.uint8)   # 5 windows: ranks get 2 + 2 + 1
     dist.init_process_group("gloo")
-    rank = dist.get_rank()
+    rank, world = dist.get_rank(), dist.get_world_size()
     d, _ = m.infer_video_depth(frames, 24, input_size=28)
     np.save(f"{out}_rank{rank}.npy", d)
+    m.result_ranks = (0,)                         # only rank 0 stitches and copies back
+    d0, fps = m.infer_video_depth(frames, 24, input_size=28)
+    assert fps == 24 and ((d0 is None) != (rank == 0)) and (rank != 0 or np.array_equal(d0, d))
+    kinds = [None] * world
+    dist.all_gather_object(kinds, f"rank{rank}:{'None' if d0 is None else 'array'}")
+    m.result_ranks = None
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
+        open(f"{out}_result_ranks.txt", "w").write(" ".join(kinds))
         d1, _ = m.infer_video_depth(frames, 24, input_size=28)
         np.save(f"{out}_single.npy", d1)
 

@@ -24,7 +24,11 @@ def declared_symbols():
 def test_header_declares_the_hot_path():
     syms = declared_symbols()
     for need in ("vda_gemm_f16", "vda_attention_f16", "vda_layernorm_f32_f16", "vda_groupnorm_nhwc_f16",
-                 "vda_temporal_attention_f16", "vda_bilinear_nhwc_f16", "vda_last_error"):
+                 "vda_temporal_attention_f16", "vda_bilinear_nhwc_f16", "vda_last_error",
+                 # fp32-operand twins
+                 "vda_gemm_f32", "vda_attention_f32", "vda_layernorm_f32_f32", "vda_groupnorm_nhwc_f32", "vda_temporal_attention_f32",
+                 # handle API
+                 "vda_create", "vda_destroy", "vda_load_weight", "vda_finalize_weights", "vda_workspace_bytes", "vda_forward"):
         assert need in syms
 
 
@@ -34,7 +38,7 @@ def test_library_exports_every_declared_symbol(libpath):
     lib = ctypes.CDLL(libpath)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libvda_hip.so lacks {missing}"
-    assert lib.vda_abi_version() == 1
+    assert lib.vda_abi_version() == 2
 
 
 def test_binding_table_matches_header(libpath):

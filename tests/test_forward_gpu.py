@@ -1,15 +1,17 @@
-"""End-to-end parity of the HIP path on the MI355X.
+"""End-to-end parity of the HIP path on the MI355X, through the product class (VideoDepthAnything -> vda_forward).
 
  (a) committed golden fixtures = outputs of the reference's own modules (oracle/gen_golden.py);
- (b) the CPU oracle on seeded inputs at sizes it finishes in seconds;
- (c) BASELINE.json's full size (ViT-L, 1x32x518x518) through size-independent properties:
-     bitwise run-to-run determinism, clip independence (B=2 == two B=1), finiteness/ReLU range.
+ (b) the CPU oracle on seeded inputs at sizes it finishes in seconds - every BASELINE.json config's model;
+ (c) BASELINE.json's full sizes through size-independent properties: bitwise run-to-run determinism, clip independence
+     (B=2 == two B=1), finiteness / ReLU range, and stitched-video == per-window forward + the host stitcher.
 
-Tolerance (stated here as north_star asks): the product computes with fp16 MFMA operands, fp32
-accumulation, fp32 residual streams and fp32 norm/softmax statistics. Against the fp32 reference:
-    relative L1  = mean|y - ref| / mean|ref|  <= 3e-3   on the final depth,
-    and <= 4e-3 on intermediate stages (taps and pyramid levels).
-north_star's 1e-3 is the bar for an fp32 path; measured values are written to gpurun_out/parity.json.
+Tolerances (relative L1 = mean|y - ref| / mean|ref| against the fp32 reference, as north_star states its bar):
+  fp32=True   (fp32 operands on exact-fp32 MFMA; the reference's --fp32 path):  <= 1e-3 on every fixture, depth and stages
+              (north_star's bar; measured values are ~1e-6..1e-5, written to gpurun_out/parity.json)
+  fp32=False  (fp16 operands, fp32 accumulate / residual streams; the reference's autocast path): per check, <= 2x the value
+              measured in round 1 (table TOL16 below; the measurement is in gpurun_out/parity.json of each run)
+Next to every mean there is a tail bound (99.9th percentile of |y - ref| <= 2e-2 * (|ref| + mean|ref|)) and a border-ring
+relative L1 (<= 2x the check's tolerance), so a localised error - a wrong one-pixel ring, one bad tile - cannot hide in the mean.
 """
 import json
 import os
@@ -21,8 +23,11 @@ import torch
 pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOL_DEPTH = 3e-3
-TOL_STAGE = 4e-3
+TOL32 = 1e-3
+# fp16-operand path: 2x the round-1 measurements (gpurun_out/parity.json at 36eef41)
+TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.nonsquare.depth": 1.4e-3, "vits.518.depth_sub": 3.0e-3,
+         "vits.518.row_sums": 2.5e-3, "video.relative": 3.6e-3, "video.metric": 4.3e-3, "vitl.2x518": 2.4e-3, "vits.4x518": 7e-4,
+         "vitl.t32": 2.4e-3, "vitl.metric_video": 4.3e-3, "resize_video": 3.6e-3}
 _measured = {}
 
 
@@ -40,12 +45,33 @@ def record(name, val):
         json.dump(_measured, f, indent=1, sort_keys=True)
 
 
-def model_for(name, seed):
+def check_map(name, y, ref, tol, tail=True):
+    """Mean relative L1, plus (for [..., H, W] maps) the tail and border-ring bounds of the module docstring."""
+    y, ref = np.asarray(y, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    e = rel_l1(y, ref)
+    record(name, e)
+    assert e < tol, f"{name}: rel-L1 {e:.3e} >= {tol:.1e}"
+    if not tail:
+        return e
+    scale = np.abs(ref).mean()
+    q = float(np.quantile(np.abs(y - ref) / (np.abs(ref) + scale), 0.999))
+    record(name + ".p999", q)
+    assert q < max(2e-2, 20 * tol), f"{name}: 99.9th percentile of the relative error is {q:.3e}"
+    if y.ndim >= 2 and min(y.shape[-2:]) >= 8:
+        ring = np.ones(y.shape[-2:], dtype=bool)
+        ring[1:-1, 1:-1] = False
+        er = float(np.abs(y - ref)[..., ring].mean() / max(np.abs(ref)[..., ring].mean(), 1e-12))
+        record(name + ".ring", er)
+        assert er < 2 * tol, f"{name}: border-ring rel-L1 {er:.3e}"
+    return e
+
+
+def model_for(name, seed, cls=None):
     from video_depth_anything_amd.config import get_config
     from video_depth_anything_amd.video_depth import VideoDepthAnything
     from video_depth_anything_amd.weights import synthetic_state_dict
     cfg = get_config(name)
-    m = VideoDepthAnything(encoder=name, features=cfg.features, out_channels=list(cfg.out_channels))
+    m = (cls or VideoDepthAnything)(encoder=name, features=cfg.features, out_channels=list(cfg.out_channels))
     sd = synthetic_state_dict(cfg, seed=seed)
     m.load_state_dict(sd, strict=True)
     return m.to("cuda").eval(), cfg, sd
@@ -55,120 +81,248 @@ def nhwc_to_nchw(t, B, h, w, Cp, C):
     return t.view(B, h, w, Cp)[..., :C].permute(0, 3, 1, 2).float().cpu().numpy()
 
 
-def test_golden_tiny_every_stage(golden_dir):
+PRECISIONS = [pytest.param(False, id="fp16"), pytest.param(True, id="fp32")]
+
+
+def tol_of(key, fp32):
+    return TOL32 if fp32 else TOL16[key]
+
+
+# ---------------------------------------------------------------- (a) reference-generated goldens
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_golden_tiny_every_stage(golden_dir, fp32):
     z = np.load(os.path.join(golden_dir, "tiny_forward.npz"))
     m, cfg, _ = model_for("tiny", int(z["sd_seed"]))
     x = torch.from_numpy(z["x"]).cuda()
-    taps, stages = [], {}
-    d = m.engine.forward(x, taps_out=taps, stages=stages)
+    d = m.forward(x, fp32=fp32)
     BT = x.shape[0] * x.shape[1]
-    for i, t in enumerate(taps):
-        e = rel_l1(t.float().cpu().numpy().reshape(z[f"tap{i}"].shape), z[f"tap{i}"])
-        record(f"tiny.tap{i}", e)
-        assert e < TOL_STAGE, f"tap{i} rel-L1 {e}"
+    tag = "tiny.f32." if fp32 else "tiny."
+    for i in range(4):
+        t, h, w, Cp = m.engine.stage(f"tap{i}")
+        check_map(f"{tag}tap{i}", t.float().cpu().numpy().reshape(z[f"tap{i}"].shape), z[f"tap{i}"], tol_of("tiny.tap", fp32), tail=False)
     chans = {"layer_1": cfg.out_channels[0], "layer_2": cfg.out_channels[1], "layer_3": cfg.out_channels[2],
              "layer_4": cfg.out_channels[3], "path_4": cfg.features, "path_3": cfg.features, "path_2": cfg.features,
              "path_1": cfg.features}
     for k, C in chans.items():
-        t, h, w, Cp = stages[k]
-        e = rel_l1(nhwc_to_nchw(t, BT, h, w, Cp, C), z[k])
-        record(f"tiny.{k}", e)
-        assert e < TOL_STAGE, f"{k} rel-L1 {e}"
-    e = rel_l1(d.cpu().numpy(), z["depth"])
-    record("tiny.depth", e)
-    assert e < TOL_DEPTH, f"depth rel-L1 {e}"
+        t, h, w, Cp = m.engine.stage(k)
+        check_map(f"{tag}{k}", nhwc_to_nchw(t, BT, h, w, Cp, C), z[k], tol_of("tiny.stage", fp32), tail=False)
+    check_map(f"{tag}depth", d.cpu().numpy(), z["depth"], tol_of("tiny.depth", fp32))
 
 
-def test_golden_vits_nonsquare(golden_dir):
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_golden_vits_nonsquare(golden_dir, fp32):
     z = np.load(os.path.join(golden_dir, "vits_forward.npz"))
     m, _, _ = model_for("vits", int(z["sd_seed"]))
-    d = m(torch.from_numpy(z["x"]).cuda())
-    e = rel_l1(d.cpu().numpy(), z["depth"])
-    record("vits.nonsquare.depth", e)
-    assert e < TOL_DEPTH, f"rel-L1 {e}"
+    d = m.forward(torch.from_numpy(z["x"]).cuda(), fp32=fp32)
+    check_map("vits.nonsquare.depth" + (".f32" if fp32 else ""), d.cpu().numpy(), z["depth"], tol_of("vits.nonsquare.depth", fp32))
 
 
-def test_golden_vits_518(golden_dir):
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_golden_vits_518(golden_dir, fp32):
     z = np.load(os.path.join(golden_dir, "vits_518.npz"))
     m, _, _ = model_for("vits", int(z["sd_seed"]))
     x = torch.randn(1, 1, 3, 518, 518, generator=torch.Generator().manual_seed(int(z["x_seed"])))
-    d = m(x.cuda()).cpu().numpy()
-    e = rel_l1(d[..., ::7, ::7], z["depth_sub"])
-    record("vits.518.depth_sub", e)
-    assert e < TOL_DEPTH, f"rel-L1 {e}"
-    e2 = rel_l1(d.sum(axis=-1), z["row_sums"])
-    record("vits.518.row_sums", e2)
-    assert e2 < TOL_DEPTH
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    sfx = ".f32" if fp32 else ""
+    check_map("vits.518.depth_sub" + sfx, d[..., ::7, ::7], z["depth_sub"], tol_of("vits.518.depth_sub", fp32))
+    check_map("vits.518.row_sums" + sfx, d.sum(axis=-1), z["row_sums"], tol_of("vits.518.row_sums", fp32), tail=False)
 
 
+@pytest.mark.parametrize("fp32", PRECISIONS)
 @pytest.mark.parametrize("name,metric", [("tiny_video.npz", False), ("tiny_metric_video.npz", True)])
-def test_golden_infer_video_depth(golden_dir, name, metric):
-    from video_depth_anything_amd.config import get_config
+def test_golden_infer_video_depth(golden_dir, name, metric, fp32):
     from video_depth_anything_amd.video_depth import MetricVideoDepthAnything, VideoDepthAnything
-    from video_depth_anything_amd.weights import synthetic_state_dict
     z = np.load(os.path.join(golden_dir, name))
-    cfg = get_config("tiny")
-    cls = MetricVideoDepthAnything if metric else VideoDepthAnything
-    m = cls(encoder="tiny", features=cfg.features, out_channels=list(cfg.out_channels))
-    m.load_state_dict(synthetic_state_dict(cfg, seed=int(z["sd_seed"])), strict=True)
-    m = m.to("cuda").eval()
-    depths, fps = m.infer_video_depth(z["frames"], 24, input_size=int(z["input_size"]), device="cuda")
+    m, _, _ = model_for("tiny", int(z["sd_seed"]), MetricVideoDepthAnything if metric else VideoDepthAnything)
+    depths, fps = m.infer_video_depth(z["frames"], 24, input_size=int(z["input_size"]), device="cuda", fp32=fp32)
     assert depths.shape == z["depths"].shape and depths.dtype == np.float32 and fps == 24
-    e = rel_l1(depths, z["depths"])
-    record(f"video.{'metric' if metric else 'relative'}", e)
-    assert e < 2 * TOL_DEPTH, f"stitched video rel-L1 {e}"     # the scale/shift fit compounds per-window error
+    key = "video.metric" if metric else "video.relative"
+    check_map(key + (".f32" if fp32 else ""), depths, z["depths"], tol_of(key, fp32))     # the scale/shift fit compounds per-window error
 
 
-def test_oracle_vits_4frames_518():
-    """ViT-S, 4 frames at 518x518 (1370 tokens/frame, stored pos-embed): HIP path vs the CPU oracle."""
+# ---------------------------------------------------------------- (b) the CPU oracle on seeded inputs
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_oracle_vits_4frames_518(fp32):
+    """ViT-S (BASELINE config 2's model), 4 frames at 518x518 (1370 tokens/frame, stored pos-embed)."""
     from oracle import vda_oracle as O
     m, cfg, sd = model_for("vits", 7)
     x = torch.randn(1, 4, 3, 518, 518, generator=torch.Generator().manual_seed(70))
     with torch.no_grad():
         ref = O.forward(sd, cfg, x).numpy()
-    d = m(x.cuda()).cpu().numpy()
-    e = rel_l1(d, ref)
-    record("vits.4x518.depth_vs_oracle", e)
-    assert e < TOL_DEPTH, f"rel-L1 {e}"
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    check_map("vits.4x518.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vits.4x518", fp32))
 
 
-def test_oracle_vitl_2frames_518():
-    """The headline model: ViT-L, 2 frames at 518x518, HIP path vs the CPU oracle (fp32)."""
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_oracle_vitl_2frames_518(fp32):
+    """The headline model (config 3): ViT-L, 2 frames at 518x518."""
     from oracle import vda_oracle as O
     m, cfg, sd = model_for("vitl", 3)
     x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(72))
     with torch.no_grad():
         ref = O.forward(sd, cfg, x).numpy()
-    d = m(x.cuda()).cpu().numpy()
-    e = rel_l1(d, ref)
-    record("vitl.2x518.depth_vs_oracle", e)
-    assert e < TOL_DEPTH, f"rel-L1 {e}"
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    check_map("vitl.2x518.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.2x518", fp32))
 
 
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_oracle_vitl_32frames_small(fp32):
+    """Config 3's temporal extent: ViT-L with the full 32-frame temporal attention (d = 128 / 32 heads of the four motion
+    modules, PE rows 0..31) at a small spatial size, 1x32x3x70x84, against the oracle."""
+    from oracle import vda_oracle as O
+    m, cfg, sd = model_for("vitl", 4)
+    x = torch.randn(1, 32, 3, 70, 84, generator=torch.Generator().manual_seed(73))
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, x).numpy()
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    check_map("vitl.32x70x84.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.t32", fp32))
+
+
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_oracle_metric_vitl_two_windows(fp32):
+    """Config 5: MetricVideoDepthAnything with its ViT-L defaults (metric_depth/video_depth_anything/video_depth.py:36-45),
+    a 40-frame video = 2 windows at a small spatial size, against the oracle's infer_video_depth(metric=True) (:132)."""
+    from oracle import vda_oracle as O
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import MetricVideoDepthAnything
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    m = MetricVideoDepthAnything()                       # vitl, features 256, out_channels [256, 512, 1024, 1024]
+    cfg = get_config("vitl")
+    assert m.cfg == cfg and m.METRIC
+    sd = synthetic_state_dict(cfg, seed=9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    frames = np.random.default_rng(31).integers(0, 256, (40, 42, 56, 3), dtype=np.uint8)
+    ref, _ = O.infer_video_depth(sd, cfg, frames, 24, input_size=42, metric=True)
+    d, fps = m.infer_video_depth(frames, 24, input_size=42, device="cuda", fp32=fp32)
+    assert d.shape == ref.shape == (40, 42, 56) and fps == 24
+    check_map("vitl.metric_video" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.metric_video", fp32))
+
+
+def test_handle_and_python_orchestration_are_bit_identical(golden_dir):
+    """vda_forward (csrc/host.hip: C++ weight packing + launch sequence) against engine.Engine (Python packing + the same
+    launches through the per-kernel ABI): bit-identical outputs on the tiny and ViT-S fixtures, both precisions."""
+    for name, fixture in (("tiny", "tiny_forward.npz"), ("vits", "vits_forward.npz")):
+        z = np.load(os.path.join(golden_dir, fixture))
+        m, _, _ = model_for(name, int(z["sd_seed"]))
+        py = m.python_engine()
+        x = torch.from_numpy(z["x"]).cuda()
+        for fp32 in (False, True):
+            a = m.forward(x, fp32=fp32).clone()
+            b = py.forward(x, fp32=fp32).clone()
+            assert torch.equal(a, b), f"{name} fp32={fp32}: {int((a != b).sum())} of {a.numel()} elements differ"
+    # a square 518 frame too (stored pos-embed, 1370 tokens, the 256-row GEMM kernels)
+    m, _, _ = model_for("vits", 11)
+    py = m.python_engine()
+    x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(74)).cuda()
+    assert torch.equal(m.forward(x, fp32=False), py.forward(x, fp32=False))
+
+
+def test_forward_precision_follows_autocast():
+    """A bare model(x) is the reference's nn.Module call: fp32 outside torch.autocast, fp16 operands inside."""
+    m, _, _ = model_for("tiny", 1)
+    x = torch.randn(1, 3, 3, 42, 56, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.autocast("cuda"):
+        a = m(x).clone()
+    assert torch.equal(a, m.forward(x, fp32=False))
+    assert torch.equal(m(x), m.forward(x, fp32=True))
+    assert not torch.equal(a, m(x))
+
+
+def test_handle_refuses_bad_state_dicts_like_torch():
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import VideoDepthAnything
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    cfg = get_config("tiny")
+    sd = synthetic_state_dict(cfg, seed=0)
+    m = VideoDepthAnything(encoder="tiny", features=cfg.features, out_channels=list(cfg.out_channels)).to("cuda")
+    bad = dict(sd)
+    del bad["head.scratch.output_conv1.bias"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        m.load_state_dict(bad, strict=True)
+    bad = dict(sd, extra=torch.zeros(1))
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        m.load_state_dict(bad, strict=True)
+    bad = dict(sd)
+    bad["pretrained.norm.weight"] = torch.zeros(7)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        m.load_state_dict(bad, strict=True)
+    # the C side says the same when driven directly (a C host has no Python checker in front of it)
+    import ctypes as C
+    from video_depth_anything_amd._lib import lib
+    t = torch.zeros(7)
+    dims = (C.c_int64 * 1)(7)
+    assert lib.vda_load_weight(m.engine._h, b"pretrained.norm.weight", C.c_void_p(t.data_ptr()), dims, 1, 0) != 0
+    assert b"size mismatch for pretrained.norm.weight" in lib.vda_last_error()
+    assert lib.vda_load_weight(m.engine._h, b"nope", C.c_void_p(t.data_ptr()), dims, 1, 0) != 0
+    assert b"Unexpected key" in lib.vda_last_error()
+    m.load_state_dict(sd, strict=True)
+    assert torch.isfinite(m.forward(torch.zeros(1, 2, 3, 28, 28).cuda(), fp32=False)).all()
+
+
+# ---------------------------------------------------------------- preprocessing resize (frames not at network size)
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_video_with_non_network_size_frames(fp32):
+    """Real-video case: 36x64 source frames, input_size 28 -> network 28x56 (aspect guard + lower-bound rule), so every window
+    goes through vda_gather_resize_normalize_u8_f32. Reference path restated: bicubic (cv2.INTER_CUBIC's definition, evaluated by
+    torch on the CPU - cv2 itself is absent, so parity with cv2's own arithmetic is unpinned) -> oracle forward per window ->
+    bilinear back to the source size -> the oracle's stitcher."""
+    import torch.nn.functional as F
+    from oracle import vda_oracle as O
+    from video_depth_anything_amd import scheduler as S
+    m, cfg, sd = model_for("tiny", 12)
+    frames = np.random.default_rng(32).integers(0, 256, (40, 36, 64, 3), dtype=np.uint8)
+    H, W = S.network_size(36, 64, 28)
+    assert (H, W) != (36, 64)
+    d, _ = m.infer_video_depth(frames, 24, input_size=28, device="cuda", fp32=fp32)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    wins = []
+    for idx in S.plan_windows(40):
+        img = torch.from_numpy(frames[idx]).float().div(255.0).permute(0, 3, 1, 2)
+        x = (F.interpolate(img, size=(H, W), mode="bicubic", align_corners=False) - mean) / std
+        with torch.no_grad():
+            y = O.forward(sd, cfg, x[None])
+            wins.append(F.interpolate(y.transpose(0, 1), size=(36, 64), mode="bilinear", align_corners=True)[:, 0].numpy())
+    ref = S.stitch_windows(wins, 40)
+    assert d.shape == ref.shape == (40, 36, 64)
+    check_map("resize_video" + (".f32" if fp32 else ""), d, ref, tol_of("resize_video", fp32))
+
+
+# ---------------------------------------------------------------- CLI / driver callers
 def test_run_cli_synthetic(tmp_path):
-    """run.py end to end with the reference's flags: frames from .npz, depths to <name>_depths.npz."""
+    """run.py end to end with the reference's flags: frames from .npz, depths to <name>_depths.npz; --fp32 is the fp32 path."""
     import subprocess
     import sys
     frames = np.random.default_rng(9).integers(0, 256, (30, 70, 84, 3), dtype=np.uint8)
     src = tmp_path / "clip.npz"
     np.savez(src, frames=frames, fps=24)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "run.py"), "--input_video", str(src), "--output_dir", str(tmp_path / "out"),
-                        "--encoder", "vits", "--input_size", "70", "--checkpoint", "synthetic", "--save_npz"],
-                       capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    d = np.load(tmp_path / "out" / "clip_depths.npz")["depths"]
-    assert d.shape == (30, 70, 84) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0
+    outs = {}
+    for flag in ([], ["--fp32"]):
+        out = tmp_path / ("out32" if flag else "out16")
+        r = subprocess.run([sys.executable, os.path.join(REPO, "run.py"), "--input_video", str(src), "--output_dir", str(out),
+                            "--encoder", "vits", "--input_size", "70", "--checkpoint", "synthetic", "--save_npz"] + flag,
+                           capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        d = np.load(out / "clip_depths.npz")["depths"]
+        assert d.shape == (30, 70, 84) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0
+        outs[bool(flag)] = d
+    e = rel_l1(outs[False], outs[True])
+    record("run_cli.fp16_vs_fp32", e)
+    assert 0 < e < 5e-3, "--fp32 must change the arithmetic (and only slightly)"
 
 
 def test_benchmark_infer_driver(tmp_path):
-    """benchmark/infer/infer.py: JSON manifest of scenes -> one float32 .npy per frame (frames supplied as .npy images)."""
+    """benchmark/infer/infer.py (the reference's second caller, always fp32=True, BGR images): its per-frame .npy equals
+    infer_video_depth(fp32=True) called directly on the same frames in RGB order."""
     import subprocess
     import sys
     rng = np.random.default_rng(10)
-    scene = []
+    scene, imgs = [], []
     os.makedirs(tmp_path / "data" / "scene0", exist_ok=True)
     for i in range(5):
-        np.save(tmp_path / "data" / "scene0" / f"{i:03d}.npy", rng.integers(0, 256, (70, 84, 3), dtype=np.uint8))
+        bgr = rng.integers(0, 256, (70, 84, 3), dtype=np.uint8)
+        np.save(tmp_path / "data" / "scene0" / f"{i:03d}.npy", bgr)
+        imgs.append(bgr)
         scene.append({"image": f"data/scene0/{i:03d}.npy"})
     man = tmp_path / "manifest.json"
     man.write_text(json.dumps({"toy": [{"scene0": scene}]}))
@@ -176,47 +330,112 @@ def test_benchmark_infer_driver(tmp_path):
                         str(tmp_path / "pred"), "--datasets", "toy", "--encoder", "vits", "--input_size", "70", "--checkpoint", "synthetic"],
                        capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    d = np.load(tmp_path / "pred" / "toy" / "data" / "scene0" / "003.npy")
-    assert d.shape == (70, 84) and d.dtype == np.float32 and np.isfinite(d).all()
+    got = np.stack([np.load(tmp_path / "pred" / "toy" / "data" / "scene0" / f"{i:03d}.npy") for i in range(5)])
+    assert got.shape == (5, 70, 84) and got.dtype == np.float32
+    m, _, _ = model_for("vits", 0)                       # --checkpoint synthetic = synthetic_state_dict(cfg, seed=0)
+    rgb = np.stack([im[:, :, ::-1] for im in imgs])
+    direct, _ = m.infer_video_depth(rgb, 1, input_size=70, device="cuda", fp32=True)
+    assert np.array_equal(got, direct), "the driver must hand RGB frames to infer_video_depth(fp32=True) and save its output unchanged"
 
 
+# ---------------------------------------------------------------- (c) full sizes through properties
 def test_batch_of_clips_equals_separate_clips():
     m, _, _ = model_for("vits", 8)
     x = torch.randn(2, 5, 3, 70, 84, generator=torch.Generator().manual_seed(71)).cuda()
-    both = m(x).clone()
-    a = m(x[:1].contiguous()).clone()
-    b = m(x[1:].contiguous()).clone()
+    both = m.forward(x, fp32=False).clone()
+    a = m.forward(x[:1].contiguous(), fp32=False).clone()
+    b = m.forward(x[1:].contiguous(), fp32=False).clone()
     assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
 
 
-def test_full_size_vitl_properties():
-    """BASELINE.json config 3: ViT-L, 1x32x518x518."""
-    m, _, _ = model_for("vitl", 0)
+@pytest.mark.parametrize("name", ["vits", "vitl"])
+def test_full_size_properties(name):
+    """BASELINE.json configs 2 and 3: ViT-S / ViT-L, 1x32x518x518, fp16 operands."""
+    m, _, _ = model_for(name, 0)
     x = torch.randn(1, 32, 3, 518, 518, generator=torch.Generator().manual_seed(0)).cuda()
-    d1 = m(x).clone()
-    d2 = m(x).clone()
+    d1 = m.forward(x, fp32=False).clone()
+    d2 = m.forward(x, fp32=False).clone()
     assert d1.shape == (1, 32, 518, 518) and d1.dtype == torch.float32
     assert torch.isfinite(d1).all() and float(d1.min()) >= 0.0
     assert float(d1.std()) > 0, "degenerate output"
     assert torch.equal(d1, d2), "forward must be bitwise deterministic (no atomics in any reduction)"
-    # clip independence at full size: frames 0..15 as their own clip differ from the 32-frame clip only through
-    # temporal attention, so instead check the B axis: a batch of the same clip twice gives identical halves.
-    d3 = m(torch.cat([x[:, :8], x[:, :8]], dim=0).contiguous())
+    # clip independence at full width: a batch of the same 8-frame clip twice gives identical halves
+    d3 = m.forward(torch.cat([x[:, :8], x[:, :8]], dim=0).contiguous(), fp32=False)
     assert torch.equal(d3[0], d3[1])
 
 
-def test_two_ranks_share_one_gpu(tmp_path):
-    """The multi-rank branch of infer_video_depth rehearsed with 2 processes on this one GPU (gloo stands in for RCCL; the
-    exchange is staged through the host): both ranks must return exactly what a single rank returns."""
+def test_full_size_vitl_fp32_against_fp16():
+    """The fp32 path at the headline shape (8 of the 32 frames to bound the run time): finite, deterministic, and within the
+    fp16 path's tolerance of it - the two paths share nothing but the launch sequence."""
+    m, _, _ = model_for("vitl", 0)
+    x = torch.randn(1, 8, 3, 518, 518, generator=torch.Generator().manual_seed(1)).cuda()
+    a = m.forward(x, fp32=True).clone()
+    b = m.forward(x, fp32=True).clone()
+    assert torch.isfinite(a).all() and float(a.min()) >= 0.0 and torch.equal(a, b)
+    e = rel_l1(m.forward(x, fp32=False).cpu().numpy(), a.cpu().numpy())
+    record("vitl.8x518.fp16_vs_fp32", e)
+    assert e < TOL16["vitl.2x518"]
+
+
+def test_long_video_equals_per_window_forward_plus_host_stitcher():
+    """A 230-frame 518x518 video (11 windows) through infer_video_depth (device gather, forward, device stitcher, streamed D2H)
+    == forward per planned window + the numpy stitcher (scheduler.stitch_windows, bit-equal to the oracle's on the CPU)."""
+    from video_depth_anything_amd import ops, scheduler as S
+    m, _, _ = model_for("vits", 13)
+    n = 230
+    frames = np.random.default_rng(33).integers(0, 256, (n, 518, 518, 3), dtype=np.uint8)
+    d, _ = m.infer_video_depth(frames, 24, input_size=518, device="cuda", fp32=False)
+    assert d.shape == (n, 518, 518) and d.dtype == np.float32 and np.isfinite(d).all() and d.min() >= 0
+    video = torch.from_numpy(frames).cuda()
+    xin = torch.empty(1, 32, 3, 518, 518, dtype=torch.float32, device="cuda")
+    wins = []
+    plan = S.plan_windows(n)
+    assert len(plan) == 11
+    for idx in plan:
+        ops.gather_normalize_u8(video, torch.tensor(idx, dtype=torch.int32, device="cuda"), xin, 32, 518, 518)
+        wins.append(m.forward(xin, fp32=False)[0].cpu().numpy())
+    ref = S.stitch_windows(wins, n)
+    # per-window depth maps are bit-identical; the only difference is the scale/shift sums (fp64 on the device, numpy's fp32
+    # closed form whose determinant cancels digits), compounded along the 10-window chain
+    e = rel_l1(d, ref)
+    record("long_video.device_vs_host_stitch", e)
+    assert e < 5e-4
+    np.testing.assert_allclose(d, ref, rtol=5e-3, atol=5e-3)
+    assert np.array_equal(d[:22], wins[0][:22]), "window 0 is stitched unscaled"
+
+
+def test_1024_frame_vitl_video_properties():
+    """BASELINE.json config 4's single-GPU content: ViT-L, 1024 frames of 518x518 = 47 windows through infer_video_depth."""
+    m, _, _ = model_for("vitl", 0)
+    n = 1024
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (64, 518, 518, 3), dtype=np.uint8)
+    frames = np.concatenate([base] * 16, axis=0)           # 1024 frames, period 64 (keeps host RAM and RNG time down)
+    d, fps = m.infer_video_depth(frames, 30, input_size=518, device="cuda", fp32=False)
+    assert d.shape == (n, 518, 518) and d.dtype == np.float32 and fps == 30
+    assert np.isfinite(d).all() and d.min() >= 0 and d.std() > 0
+    # window 0 is stitched unscaled (video_depth.py:219-224): its first frames equal a plain forward of those frames
+    from video_depth_anything_amd import ops
+    xin = torch.empty(1, 32, 3, 518, 518, dtype=torch.float32, device="cuda")
+    ops.gather_normalize_u8(torch.from_numpy(frames[:32]).cuda(), torch.arange(32, dtype=torch.int32, device="cuda"), xin, 32, 518, 518)
+    w0 = m.forward(xin, fp32=False)[0].cpu().numpy()
+    assert np.array_equal(d[:22], w0[:22])
+
+
+def test_ranks_share_one_gpu(tmp_path):
+    """The multi-rank branch of infer_video_depth rehearsed with 3 processes on this one GPU, 5 windows (uneven shards 2+2+1;
+    gloo stands in for RCCL, the exchange is staged through the host): every rank must return exactly what a single rank returns,
+    and a rank outside result_ranks must return None."""
     import subprocess
     import sys
     out = tmp_path / "r"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
            "--master-port", "29741", os.path.join(REPO, "tests", "_gpu_ranks_worker.py"), str(out)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     single = np.load(f"{out}_single.npy")
-    for rank in (0, 1):
+    for rank in range(3):
         d = np.load(f"{out}_rank{rank}.npy")
-        assert d.shape == single.shape == (60, 28, 42)
+        assert d.shape == single.shape == (100, 28, 42)
         assert np.array_equal(d, single), f"rank {rank} differs from the single-rank result"
+    assert open(f"{out}_result_ranks.txt").read() == "rank0:array rank1:None rank2:None"

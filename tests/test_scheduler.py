@@ -51,7 +51,7 @@ def test_plan_rejects_empty():
 
 @pytest.mark.parametrize("W,G", [(47, 8), (2, 8), (5, 2), (8, 8), (1, 1), (3, 4)])
 def test_shards_partition_all_windows(W, G):
-    got = [k for r in range(G) for k in S.shard_windows(W, G, r)]
+    got = sorted(k for r in range(G) for k in S.shard_windows(W, G, r))
     assert got == list(range(W))
     sizes = [len(S.shard_windows(W, G, r)) for r in range(G)]
     assert max(sizes) - min(sizes) <= 1
@@ -114,15 +114,24 @@ def test_run_windows_single_rank_reproduces_reference_video(golden_dir):
     assert err < 5e-5
 
 
-def test_two_ranks_over_gloo_equal_one_rank(tmp_path):
-    """world_size 2, gloo: block-partitioned windows + one all-gather + stitch == single-process result."""
+@pytest.mark.parametrize("world,n_frames", [(2, 60), (3, 100)], ids=["2ranks_3windows", "3ranks_5windows"])
+def test_ranks_over_gloo_equal_one_rank(tmp_path, world, n_frames):
+    """gloo, world size 2 and 3 (uneven shards: 2+1 and 2+2+1 windows): the round-robin schedule of drive_windows - the one the
+    device path runs - with its per-round all-gather and two-slot rings == the single-process result, on every rank."""
     out = tmp_path / "r"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29731", os.path.join(REPO, "tests", "_gloo_worker.py"), str(out)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29731 + world), os.path.join(REPO, "tests", "_gloo_worker.py"), str(out), str(n_frames)]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    a, b = np.load(str(out) + "_rank0.npy"), np.load(str(out) + "_rank1.npy")
     ref = np.load(str(out) + "_single.npy")
-    np.testing.assert_array_equal(a, b)
-    np.testing.assert_array_equal(a, ref)
+    assert ref.shape == (n_frames, 28, 42)
+    for rank in range(world):
+        np.testing.assert_array_equal(np.load(f"{out}_rank{rank}.npy"), ref)
+
+
+def test_round_robin_shards_cover_every_window_once():
+    for nwin, world in [(47, 8), (3, 2), (5, 3), (1, 4), (8, 8)]:
+        got = sorted(k for r in range(world) for k in S.shard_windows(nwin, world, r))
+        assert got == list(range(nwin))
+        assert max(len(S.shard_windows(nwin, world, r)) for r in range(world)) == S.rounds(nwin, world)

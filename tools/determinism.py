@@ -77,12 +77,13 @@ if len(sys.argv) > 2:
     sd = {k: (torch.randn(s, generator=gg) * (0.02 if len(s) > 1 else 0.1) + (0 if len(s) > 1 else 1)) for k, s in state_dict_spec(cfg).items()}
     m = VideoDepthAnything(encoder="vitl", features=cfg.features, out_channels=list(cfg.out_channels)); m.load_state_dict(sd); m = m.to("cuda")
     x = torch.randn(1, 32, 3, 518, 518, generator=gg).cuda()
+    PE = m.python_engine()      # the Python launch sequence exposes every stage; bit-identical to vda_forward
     taps0, st0 = [], {}
-    ref = m.engine.forward(x, taps_out=taps0, stages=st0).clone()
+    ref = PE.forward(x, taps_out=taps0, stages=st0).clone()
     taps0 = [t.clone() for t in taps0]; st0 = {k: v[0].clone() for k, v in st0.items()}
     for it in range(3):
         taps, st = [], {}
-        d = m.engine.forward(x, taps_out=taps, stages=st)
+        d = PE.forward(x, taps_out=taps, stages=st)
         msg = []
         for i, t in enumerate(taps):
             if not torch.equal(t, taps0[i]): msg.append(f"tap{i}")

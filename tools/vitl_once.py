@@ -13,5 +13,5 @@ sd = {k: (torch.randn(s, generator=g) * 0.02 if len(s) > 1 else torch.ones(s)) f
 m = VideoDepthAnything(encoder=enc, features=cfg.features, out_channels=list(cfg.out_channels))
 m.load_state_dict(sd); m = m.to("cuda")
 x = torch.randn(1, 32, 3, 518, 518, generator=g).cuda()
-d = m(x); torch.cuda.synchronize()
+d = m.forward(x, fp32=False); torch.cuda.synchronize()
 print("done", float(d.mean()))

@@ -25,29 +25,61 @@ class GemmArgs(C.Structure):
     ]
 
 
-_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+class Config(C.Structure):
+    """vda_config (include/vda.h)."""
+    _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("taps", C.c_int32 * 4),
+                ("features", C.c_int32), ("out_channels", C.c_int32 * 4), ("num_frames", C.c_int32)]
+
+
+PREC_F16, PREC_F32 = 0, 1
+DTYPE_F32 = 0
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     "vda_last_error": (C.c_char_p, []),
     "vda_abi_version": (_i, []),
     "vda_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
+    "vda_gemm_f32": (_i, [C.POINTER(GemmArgs), _vp]),
     "vda_gemm_set_variant": (_i, [_i]),
     "vda_gemm_last_kernel": (C.c_char_p, []),
     "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "vda_layernorm_f32_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
+    "vda_groupnorm_nhwc_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "vda_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_attention_set_variant": (_i, [_i]),
     "vda_temporal_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_temporal_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_temporal_attention_set_variant": (_i, [_i]),
     "vda_bilinear_nhwc_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "vda_bilinear_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_bilinear_plane_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_patchify_f32_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_patchify_f32_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_pos_embed_resample_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_cls_rows_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "vda_head_out_f16_f32": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
+    "vda_head_out_f32_f32": (_i, [_vp, _vp, _f, _vp, _ll, _i, _vp]),
     "vda_depth_tail_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_normalize_u8_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_gather_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "vda_gather_resize_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_lsq_scale_shift_f32": (_i, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
     "vda_stitch_window_f32": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp]),
+    # handle API
+    "vda_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
+    "vda_destroy": (_i, [_vp]),
+    "vda_num_weights": (_i, [_vp]),
+    "vda_load_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i, _i]),
+    "vda_finalize_weights": (_i, [_vp]),
+    "vda_workspace_bytes": (C.c_int64, [_vp, _i, _i, _i, _i, _i]),
+    "vda_set_workspace": (_i, [_vp, _vp, C.c_int64]),
+    "vda_prepare": (_i, [_vp, _i, _i, _i, _i, _i]),
+    "vda_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vda_debug_copy": (_i, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
+    "vda_profile_start": (_i, [_vp, _i]),
+    "vda_profile_stop": (_i, [_vp, C.c_char_p, _i]),
 }
 
 

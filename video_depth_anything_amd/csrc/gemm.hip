@@ -174,16 +174,8 @@ __global__ void __launch_bounds__(NTHREADS) gemm_kernel(const vda_gemm_args p) {
 template <int BM, int BN, int AMODE>
 int launch(const vda_gemm_args& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AMODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return 2;
-        }
-        attr_set = true;
-    }
+    static VdaKernelDeviceState dev_state;
+    if (vda_prepare_kernel(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AMODE>), smem, dev_state) < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AMODE>), dim3(nbm * nbn), dim3(NTHREADS), smem, s, a);
     VDA_LAUNCH_CHECK();

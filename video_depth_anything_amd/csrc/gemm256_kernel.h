@@ -296,22 +296,9 @@ int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
     constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + 8 * 8192;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    static int num_cu = 0;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<BN, AMODE, EPI>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return 2;
-        }
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (num_cu < 8) num_cu = 8;
-        num_cu &= ~7;                           // the XCD grouping wants a multiple of 8 workgroups
-        attr_set = true;
-    }
+    static VdaKernelDeviceState dev_state;
+    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256_kernel<BN, AMODE, EPI>), smem, dev_state);
+    if (num_cu < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU

@@ -38,8 +38,8 @@ __device__ __forceinline__ float segment_sum(float v, int lane) {
     return v;
 }
 
-template <int LPR, int NCH>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ in, h16* __restrict__ out,
+template <int LPR, int NCH, typename OT>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ in, OT* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, int rows, int D, int group, int skip,
                                                         const float* __restrict__ pe, int pe_rows_per_step, int pe_steps) {
@@ -85,12 +85,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         orow = g * (group - skip) + (i - skip);
     }
     const float* per = pe ? pe + (size_t)((row / pe_rows_per_step) % pe_steps) * D : nullptr;
-    h16* dst = out + (size_t)orow * D;
+    OT* dst = out + (size_t)orow * D;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = sub + c * LPR;
         if (ch < nchunk) {
-            h16x8 o;
+            float o[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const f32x4 ww = *reinterpret_cast<const f32x4*>(w + ch * 8 + h * 4);
@@ -98,9 +98,9 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
                 f32x4 y = (v[c][h] - mean) * rstd * ww + bb;
                 if (per) y += *reinterpret_cast<const f32x4*>(per + ch * 8 + h * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[h * 4 + e] = (h16)y[e];
+                for (int e = 0; e < 4; ++e) o[h * 4 + e] = y[e];
             }
-            *reinterpret_cast<h16x8*>(dst + ch * 8) = o;
+            store8(dst + ch * 8, o);
         }
     }
 }
@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
 // ---------------------------------------------------------------- GroupNorm
 // Stage 1: grid (chunks, frames). A block sums x and x^2 per channel over its rows of one frame,
 // folds channels into groups in a fixed order, writes partial[frame][chunk][group][2].
-__global__ void __launch_bounds__(256) groupnorm_partial_kernel(const h16* __restrict__ in, float* __restrict__ partial,
+template <typename T>
+__global__ void __launch_bounds__(256) groupnorm_partial_kernel(const T* __restrict__ in, float* __restrict__ partial,
                                                                 int hw, int C, int groups, int chunks) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [rows_par][C][2] then [C][2]
     const int frame = blockIdx.y, chunk = blockIdx.x;
@@ -122,14 +123,14 @@ __global__ void __launch_bounds__(256) groupnorm_partial_kernel(const h16* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (rl < rows_par) {
-        const h16* base = in + (size_t)frame * hw * C + vi * 8;
+        const T* base = in + (size_t)frame * hw * C + vi * 8;
         for (int r = r0 + rl; r < r1; r += rows_par) {
-            const h16x8 x = *reinterpret_cast<const h16x8*>(base + (size_t)r * C);
+            float x[8];
+            load8(base + (size_t)r * C, x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float f = (float)x[e];
-                s[e] += f;
-                q[e] += f * f;
+                s[e] += x[e];
+                q[e] += x[e] * x[e];
             }
         }
 #pragma unroll
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(256) groupnorm_partial_kernel(const h16* __res
 }
 
 // Stage 2: grid (row blocks, frames). Combine the frame's partials (double, fixed order), normalise.
-__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const h16* __restrict__ in, h16* __restrict__ out,
+template <typename T>
+__global__ void __launch_bounds__(256) groupnorm_apply_kernel(const T* __restrict__ in, T* __restrict__ out,
                                                               const float* __restrict__ w, const float* __restrict__ b,
                                                               const float* __restrict__ partial, float eps, int hw, int C,
                                                               int groups, int chunks, int rows_per_block) {
@@ -192,23 +194,23 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const h16* __restr
     for (int idx = tid; idx < (r1 - r0) * nv; idx += 256) {
         const int r = r0 + idx / nv, vi = idx % nv;
         const size_t off = fbase + (size_t)r * C + vi * 8;
-        const h16x8 x = *reinterpret_cast<const h16x8*>(in + off);
-        h16x8 y;
+        float x[8], y[8];
+        load8(in + off, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = vi * 8 + e;
             const int g = c / cpg;
-            y[e] = (h16)(((float)x[e] - mean_s[g]) * rstd_s[g] * w[c] + b[c]);
+            y[e] = (x[e] - mean_s[g]) * rstd_s[g] * w[c] + b[c];
         }
-        *reinterpret_cast<h16x8*>(out + off) = y;
+        store8(out + off, y);
     }
 }
 
 }  // namespace
 
-extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const float* b, float eps, int rows, int D,
-                                     int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
-                                     vda_stream_t stream) {
+template <typename OT>
+static int layernorm_launch(const float* in, OT* out, const float* w, const float* b, float eps, int rows, int D, int group, int skip,
+                            const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream) {
     VDA_REQUIRE(in && out && w && b, "vda_layernorm: null pointer");
     VDA_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048, "vda_layernorm: D=%d must be a multiple of 8 and <= 2048", D);
     VDA_REQUIRE(group == 0 || (group > 0 && skip >= 0 && skip < group && rows % group == 0), "vda_layernorm: bad group/skip");
@@ -218,9 +220,9 @@ extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w,
                 "vda_layernorm: 16-byte alignment required");
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = D / 8;
-#define VDA_LN_LAUNCH(LPR, NCH)                                                                                               \
-    hipLaunchKernelGGL((layernorm_kernel<LPR, NCH>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, in, \
-                       (h16*)out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps)
+#define VDA_LN_LAUNCH(LPR, NCH)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_kernel<LPR, NCH, OT>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, in, \
+                       out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps)
     if (nchunk <= 8) VDA_LN_LAUNCH(8, 1);
     else if (nchunk <= 16) VDA_LN_LAUNCH(16, 1);
     else if (nchunk <= 32) VDA_LN_LAUNCH(32, 1);
@@ -232,20 +234,44 @@ extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w,
     return 0;
 }
 
-extern "C" int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps, int frames, int hw,
-                                      int C, int groups, float* partial, int chunks, vda_stream_t stream) {
+extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const float* b, float eps, int rows, int D,
+                                     int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
+                                     vda_stream_t stream) {
+    return layernorm_launch<h16>(in, (h16*)out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+}
+
+extern "C" int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const float* b, float eps, int rows, int D,
+                                     int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
+                                     vda_stream_t stream) {
+    return layernorm_launch<float>(in, out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+}
+
+template <typename T>
+static int groupnorm_launch(const T* in, T* out, const float* w, const float* b, float eps, int frames, int hw, int C, int groups,
+                            float* partial, int chunks, vda_stream_t stream) {
     VDA_REQUIRE(in && out && w && b && partial, "vda_groupnorm: null pointer");
     VDA_REQUIRE(frames > 0 && hw > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && C % 8 == 0 && C <= 1024,
                 "vda_groupnorm: bad geometry C=%d groups=%d", C, groups);
     VDA_REQUIRE(chunks > 0 && chunks <= hw, "vda_groupnorm: chunks=%d out of range", chunks);
+    VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "vda_groupnorm: 16-byte alignment required");
     const int nv = C / 8, rows_par = 256 / nv;
     const size_t smem = ((size_t)rows_par * C * 2 + (size_t)C * 2) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(chunks, frames), dim3(256), smem, s, (const h16*)in, partial, hw, C, groups, chunks);
+    hipLaunchKernelGGL((groupnorm_partial_kernel<T>), dim3(chunks, frames), dim3(256), smem, s, in, partial, hw, C, groups, chunks);
     VDA_LAUNCH_CHECK();
     const int rows_per_block = 32;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((hw + rows_per_block - 1) / rows_per_block, frames), dim3(256), 0, s,
-                       (const h16*)in, (h16*)out, w, b, partial, eps, hw, C, groups, chunks, rows_per_block);
+    hipLaunchKernelGGL((groupnorm_apply_kernel<T>), dim3((hw + rows_per_block - 1) / rows_per_block, frames), dim3(256), 0, s, in, out, w,
+                       b, partial, eps, hw, C, groups, chunks, rows_per_block);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps, int frames, int hw,
+                                      int C, int groups, float* partial, int chunks, vda_stream_t stream) {
+    return groupnorm_launch<h16>((const h16*)in, (h16*)out, w, b, eps, frames, hw, C, groups, partial, chunks, stream);
+}
+
+extern "C" int vda_groupnorm_nhwc_f32(const float* in, float* out, const float* w, const float* b, float eps, int frames, int hw,
+                                      int C, int groups, float* partial, int chunks, vda_stream_t stream) {
+    return groupnorm_launch<float>(in, out, w, b, eps, frames, hw, C, groups, partial, chunks, stream);
 }

@@ -17,15 +17,16 @@ __device__ __forceinline__ void lerp_coord(int dst, int in, int outn, int& i0, i
 
 // Block = one output row (b, Y): the row's two source rows and vertical weight are block constants, a thread walks
 // (X, 8-channel vector) pairs with 32-bit index math only (the flat-index version spent its time in 64-bit div/mod).
-__global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const h16* __restrict__ in, h16* __restrict__ out,
-                                                            const h16* __restrict__ add, int B, int h, int w, int H, int W, int C) {
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            const T* __restrict__ add, int B, int h, int w, int H, int W, int C) {
     const int nv = C >> 3;
     const int Y = blockIdx.x, b = blockIdx.y;
     int y0, y1;
     float wy;
     lerp_coord(Y, h, H, y0, y1, wy);
-    const h16* r0 = in + ((size_t)b * h + y0) * w * C;
-    const h16* r1 = in + ((size_t)b * h + y1) * w * C;
+    const T* r0 = in + ((size_t)b * h + y0) * w * C;
+    const T* r1 = in + ((size_t)b * h + y1) * w * C;
     const size_t orow = ((size_t)b * H + Y) * W * C;
     const float xscale = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const int n = W * nv;
@@ -34,20 +35,19 @@ __global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const h16* __restric
         const float src = xscale * (float)X;
         const int x0 = min((int)src, w - 1), x1 = min(x0 + 1, w - 1);
         const float wx = src - (float)x0;
-        const h16x8 a00 = *reinterpret_cast<const h16x8*>(r0 + x0 * C + v * 8);
-        const h16x8 a01 = *reinterpret_cast<const h16x8*>(r0 + x1 * C + v * 8);
-        const h16x8 a10 = *reinterpret_cast<const h16x8*>(r1 + x0 * C + v * 8);
-        const h16x8 a11 = *reinterpret_cast<const h16x8*>(r1 + x1 * C + v * 8);
-        h16x8 ad = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (add) ad = *reinterpret_cast<const h16x8*>(add + orow + (size_t)i * 8);
-        h16x8 o;
+        float a00[8], a01[8], a10[8], a11[8], ad[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[8];
+        load8(r0 + x0 * C + v * 8, a00);
+        load8(r0 + x1 * C + v * 8, a01);
+        load8(r1 + x0 * C + v * 8, a10);
+        load8(r1 + x1 * C + v * 8, a11);
+        if (add) load8(add + orow + (size_t)i * 8, ad);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float top = (float)a00[e] * (1.f - wx) + (float)a01[e] * wx;
-            const float bot = (float)a10[e] * (1.f - wx) + (float)a11[e] * wx;
-            o[e] = (h16)(top * (1.f - wy) + bot * wy + (float)ad[e]);
+            const float top = a00[e] * (1.f - wx) + a01[e] * wx;
+            const float bot = a10[e] * (1.f - wx) + a11[e] * wx;
+            o[e] = top * (1.f - wy) + bot * wy + ad[e];
         }
-        *reinterpret_cast<h16x8*>(out + orow + (size_t)i * 8) = o;
+        store8(out + orow + (size_t)i * 8, o);
     }
 }
 
@@ -74,7 +74,8 @@ __global__ void __launch_bounds__(256) bilinear_plane_kernel(const float* __rest
 
 // Block = one patch row of one frame: reads 3*14 image rows (coalesced), scatters them into the
 // pw patch rows of the GEMM A matrix (column = c*196 + ky*14 + kx).
-__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ x, h16* __restrict__ out, int H, int W, int Kpad) {
+template <typename OT>
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ x, OT* __restrict__ out, int H, int W, int Kpad) {
     const int pw = W / 14, ph = H / 14;
     const int py = blockIdx.x, b = blockIdx.y;
     const int n = 3 * 14 * W;
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__
         const int px = xx / 14, kx = xx - px * 14;
         if (px >= pw) continue;
         const float v = x[(((size_t)b * 3 + c) * H + py * 14 + ky) * W + xx];
-        out[((size_t)(b * ph + py) * pw + px) * Kpad + c * 196 + ky * 14 + kx] = (h16)v;
+        out[((size_t)(b * ph + py) * pw + px) * Kpad + c * 196 + ky * 14 + kx] = (OT)v;
     }
 }
 
@@ -96,17 +97,19 @@ __global__ void cls_rows_kernel(float* __restrict__ tok, const float* __restrict
     tok[(size_t)b * (P + 1) * D + c] = cls[c] + pos[c];
 }
 
-__global__ void __launch_bounds__(256) head_out_kernel(const h16* __restrict__ in, const float* __restrict__ w, float bias,
-                                                       float* __restrict__ out, int rows, int Cpad) {
+template <typename T>
+__global__ void __launch_bounds__(256) head_out_kernel(const T* __restrict__ in, const float* __restrict__ w, float bias,
+                                                       float* __restrict__ out, long long rows, int Cpad) {
     // 4 lanes per row, 8 channels each (32 live channels), reduced with two shuffles.
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t row = gid >> 2;
     const int part = (int)(gid & 3);
     float a = 0.f;
     if (row < (size_t)rows) {
-        const h16x8 x = *reinterpret_cast<const h16x8*>(in + row * Cpad + part * 8);
+        float x[8];
+        load8(in + row * Cpad + part * 8, x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a += (float)x[e] * w[part * 8 + e];
+        for (int e = 0; e < 8; ++e) a += x[e] * w[part * 8 + e];
     }
     a += __shfl_xor(a, 1, 64);
     a += __shfl_xor(a, 2, 64);
@@ -145,6 +148,90 @@ __global__ void __launch_bounds__(256) gather_normalize_u8_kernel(const uint8_t*
     }
 }
 
+// ---- bicubic resampling (a = -0.75, half-pixel centres, taps clamped to the border): the definition shared by
+// cv2.resize(INTER_CUBIC) (util/transform.py:113) and F.interpolate(mode='bicubic', align_corners=False) (dinov2.py:196-203).
+__device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    c[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    c[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    c[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    c[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+// Window gather + resize-to-network-size + normalise in one pass (video_depth.py:197-201, util/transform.py:109-147):
+// output pixel (i, :, Y, X) of the fp32 NCHW clip = normalise( bicubic( frame idx[i] / 255 ) ). The reference resizes the
+// [0,1] image and then normalises; so does this (the horizontal pass first, like cv2's separable filter).
+__global__ void __launch_bounds__(256) gather_resize_normalize_kernel(const uint8_t* __restrict__ video, const int* __restrict__ idx,
+                                                                      float* __restrict__ out, int n, int H0, int W0, int H, int W,
+                                                                      float sy, float sx) {
+    const size_t hw = (size_t)H * W, total = (size_t)n * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t fr = i / hw, pix = i - fr * hw;
+        const int Y = (int)(pix / W), X = (int)(pix - (size_t)Y * W);
+        const float fy = ((float)Y + 0.5f) * sy - 0.5f, fx = ((float)X + 0.5f) * sx - 0.5f;
+        const float y0f = floorf(fy), x0f = floorf(fx);
+        float cy[4], cx[4];
+        cubic_coeffs(fy - y0f, cy);
+        cubic_coeffs(fx - x0f, cx);
+        const int iy = (int)y0f, ix = (int)x0f;
+        const uint8_t* f = video + (size_t)idx[fr] * H0 * W0 * 3;
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), H0 - 1);
+            float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xx = min(max(ix - 1 + b, 0), W0 - 1);
+                const uint8_t* p = f + ((size_t)yy * W0 + xx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) row[c] += cx[b] * ((float)p[c] / 255.0f);
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] += cy[a] * row[c];
+        }
+        const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[(fr * 3 + c) * hw + pix] = (float)(((double)acc[c] - mean[c]) / stdv[c]);
+    }
+}
+
+// Positional-embedding grid [1 + g*g, D] -> [1 + ph*pw, D] (dinov2.py:185-210): row 0 (cls) copied, the g x g patch grid
+// resampled with the reference's explicit scale factors (inv_sy = 1 / ((ph + 0.1) / g), likewise x). Token-major, so the
+// channel axis is contiguous: one thread per (token, channel).
+__global__ void __launch_bounds__(256) pos_embed_resample_kernel(const float* __restrict__ pe, float* __restrict__ out, int g, int ph,
+                                                                 int pw, int D, float inv_sy, float inv_sx) {
+    const size_t total = (size_t)(1 + ph * pw) * D;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int tok = (int)(i / D), d = (int)(i - (size_t)tok * D);
+        if (tok == 0) {
+            out[i] = pe[d];
+            continue;
+        }
+        const int Y = (tok - 1) / pw, X = (tok - 1) - Y * pw;
+        const float fy = inv_sy * ((float)Y + 0.5f) - 0.5f, fx = inv_sx * ((float)X + 0.5f) - 0.5f;
+        const float y0f = floorf(fy), x0f = floorf(fx);
+        float cy[4], cx[4];
+        cubic_coeffs(fy - y0f, cy);
+        cubic_coeffs(fx - x0f, cx);
+        const int iy = (int)y0f, ix = (int)x0f;
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), g - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int xx = min(max(ix - 1 + b, 0), g - 1);
+                row += cx[b] * pe[(size_t)(1 + yy * g + xx) * D + d];
+            }
+            acc += cy[a] * row;
+        }
+        out[i] = acc;
+    }
+}
+
 inline unsigned capped_grid(size_t work_items) {
     size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 16;
@@ -153,16 +240,25 @@ inline unsigned capped_grid(size_t work_items) {
 
 }  // namespace
 
-extern "C" int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add, int B, int h, int w, int H, int W, int C,
-                                     vda_stream_t stream) {
+template <typename T>
+static int bilinear_nhwc_launch(const T* in, T* out, const T* add, int B, int h, int w, int H, int W, int C, vda_stream_t stream) {
     VDA_REQUIRE(in && out, "vda_bilinear_nhwc: null pointer");
     VDA_REQUIRE(B > 0 && h > 0 && w > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "vda_bilinear_nhwc: bad geometry");
     VDA_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)add & 15) == 0, "vda_bilinear_nhwc: alignment");
     VDA_REQUIRE(B <= 65535 && (long long)w * C < (1ll << 31) && (long long)W * C < (1ll << 31), "vda_bilinear_nhwc: row too large");
-    hipLaunchKernelGGL(bilinear_nhwc_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, (const h16*)in, (h16*)out,
-                       (const h16*)add, B, h, w, H, W, C);
+    hipLaunchKernelGGL((bilinear_nhwc_kernel<T>), dim3(H, B), dim3(256), 0, (hipStream_t)stream, in, out, add, B, h, w, H, W, C);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vda_bilinear_nhwc_f16(const void* in, void* out, const void* add, int B, int h, int w, int H, int W, int C,
+                                     vda_stream_t stream) {
+    return bilinear_nhwc_launch<h16>((const h16*)in, (h16*)out, (const h16*)add, B, h, w, H, W, C, stream);
+}
+
+extern "C" int vda_bilinear_nhwc_f32(const float* in, float* out, const float* add, int B, int h, int w, int H, int W, int C,
+                                     vda_stream_t stream) {
+    return bilinear_nhwc_launch<float>(in, out, add, B, h, w, H, W, C, stream);
 }
 
 extern "C" int vda_bilinear_plane_f32(const float* in, float* out, int B, int h, int w, int H, int W, int relu, vda_stream_t stream) {
@@ -174,13 +270,22 @@ extern "C" int vda_bilinear_plane_f32(const float* in, float* out, int B, int h,
     return 0;
 }
 
-extern "C" int vda_patchify_f32_f16(const float* x, void* out, int B, int H, int W, int Kpad, vda_stream_t stream) {
+template <typename OT>
+static int patchify_launch(const float* x, OT* out, int B, int H, int W, int Kpad, vda_stream_t stream) {
     VDA_REQUIRE(x && out, "vda_patchify: null pointer");
     VDA_REQUIRE(B > 0 && H > 0 && W > 0 && H % 14 == 0 && W % 14 == 0, "vda_patchify: H=%d W=%d must be multiples of 14", H, W);
     VDA_REQUIRE(Kpad >= 588, "vda_patchify: Kpad=%d < 588", Kpad);
-    hipLaunchKernelGGL(patchify_kernel, dim3(H / 14, B), dim3(256), 0, (hipStream_t)stream, x, (h16*)out, H, W, Kpad);
+    hipLaunchKernelGGL((patchify_kernel<OT>), dim3(H / 14, B), dim3(256), 0, (hipStream_t)stream, x, out, H, W, Kpad);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vda_patchify_f32_f16(const float* x, void* out, int B, int H, int W, int Kpad, vda_stream_t stream) {
+    return patchify_launch<h16>(x, (h16*)out, B, H, W, Kpad, stream);
+}
+
+extern "C" int vda_patchify_f32_f32(const float* x, float* out, int B, int H, int W, int Kpad, vda_stream_t stream) {
+    return patchify_launch<float>(x, out, B, H, W, Kpad, stream);
 }
 
 extern "C" int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int P, int D, vda_stream_t stream) {
@@ -190,14 +295,23 @@ extern "C" int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, 
     return 0;
 }
 
-extern "C" int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream) {
+template <typename T>
+static int head_out_launch(const T* in, const float* w, float bias, float* out, long long rows, int Cpad, vda_stream_t stream) {
     VDA_REQUIRE(in && w && out && rows > 0, "vda_head_out: bad arguments");
     VDA_REQUIRE(Cpad >= 32 && Cpad % 8 == 0 && ((uintptr_t)in & 15) == 0, "vda_head_out: Cpad=%d must be >=32, multiple of 8", Cpad);
     const size_t threads = (size_t)rows * 4;
-    hipLaunchKernelGGL(head_out_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const h16*)in, w,
-                       bias, out, rows, Cpad);
+    hipLaunchKernelGGL((head_out_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, w, bias, out,
+                       rows, Cpad);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream) {
+    return head_out_launch<h16>((const h16*)in, w, bias, out, rows, Cpad, stream);
+}
+
+extern "C" int vda_head_out_f32_f32(const float* in, const float* w, float bias, float* out, long long rows, int Cpad, vda_stream_t stream) {
+    return head_out_launch<float>(in, w, bias, out, rows, Cpad, stream);
 }
 
 extern "C" int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream) {
@@ -212,6 +326,27 @@ extern "C" int vda_gather_normalize_u8_f32(const uint8_t* video, const int32_t* 
     VDA_REQUIRE(video && idx && out && n > 0 && n_video > 0 && H > 0 && W > 0, "vda_gather_normalize_u8: bad arguments");
     hipLaunchKernelGGL(gather_normalize_u8_kernel, dim3(capped_grid((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, video,
                        (const int*)idx, out, n, H, W);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_gather_resize_normalize_u8_f32(const uint8_t* video, const int32_t* idx, float* out, int n, int n_video, int H0,
+                                                  int W0, int H, int W, vda_stream_t stream) {
+    VDA_REQUIRE(video && idx && out && n > 0 && n_video > 0 && H0 > 0 && W0 > 0 && H > 0 && W > 0, "vda_gather_resize_normalize_u8: bad arguments");
+    const float sy = (float)H0 / (float)H, sx = (float)W0 / (float)W;
+    hipLaunchKernelGGL(gather_resize_normalize_kernel, dim3(capped_grid((size_t)n * H * W)), dim3(256), 0, (hipStream_t)stream, video,
+                       (const int*)idx, out, n, H0, W0, H, W, sy, sx);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_pos_embed_resample_f32(const float* pe, float* out, int g, int ph, int pw, int D, vda_stream_t stream) {
+    VDA_REQUIRE(pe && out && g > 0 && ph > 0 && pw > 0 && D > 0, "vda_pos_embed_resample: bad arguments");
+    // dinov2.py:194-203: scale_factor = ((ph + 0.1) / g, (pw + 0.1) / g) in Python floats; ATen maps a destination index with
+    // the fp32 value of 1 / scale_factor
+    const float inv_sy = (float)(1.0 / ((double)(ph + 0.1) / (double)g)), inv_sx = (float)(1.0 / ((double)(pw + 0.1) / (double)g));
+    hipLaunchKernelGGL(pos_embed_resample_kernel, dim3(capped_grid((size_t)(1 + ph * pw) * D)), dim3(256), 0, (hipStream_t)stream, pe, out,
+                       g, ph, pw, D, inv_sy, inv_sx);
     VDA_LAUNCH_CHECK();
     return 0;
 }

@@ -18,27 +18,27 @@ namespace {
 
 constexpr int TMAX = 32;
 
-template <int D>
-__global__ void __launch_bounds__(256) tattn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int T, int hw, int C,
+template <int D, typename T>
+__global__ void __launch_bounds__(256) tattn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Tn, int hw, int C,
                                                     int hg) {
     extern __shared__ __attribute__((aligned(16))) char smem_t[];
-    const int CB = hg * D, RS = CB + 8;                      // channels per block, padded LDS row stride (halves)
-    h16* lq = reinterpret_cast<h16*>(smem_t);
-    h16* lk = lq + TMAX * RS;
-    h16* lv = lk + TMAX * RS;
+    const int CB = hg * D, RS = CB + 8;                      // channels per block, padded LDS row stride (elements)
+    T* lq = reinterpret_cast<T*>(smem_t);
+    T* lk = lq + TMAX * RS;
+    T* lv = lk + TMAX * RS;
     float* lp = reinterpret_cast<float*>(lv + TMAX * RS);   // [4 waves][16][33]
 
     const int p = blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- stage q, k, v of this pixel / head group: rows f = 0..T-1 (zero-filled above T)
-    const int vpr = CB >> 3;                                 // 16-byte vectors per (row, tensor)
+    // ---- stage q, k, v of this pixel / head group: rows f = 0..Tn-1 (zero-filled above Tn)
+    const int vpr = CB >> 3;                                 // 8-element vectors per (row, tensor)
     for (int idx = tid; idx < TMAX * 3 * vpr; idx += 256) {
         const int f = idx / (3 * vpr), rem = idx - f * 3 * vpr;
         const int which = rem / vpr, v = rem - which * vpr;
-        h16x8 x = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (f < T) x = *reinterpret_cast<const h16x8*>(qkv + ((size_t)f * hw + p) * (3 * (size_t)C) + which * C + g * CB + v * 8);
-        *reinterpret_cast<h16x8*>(lq + which * TMAX * RS + f * RS + v * 8) = x;
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (f < Tn) load8(qkv + ((size_t)f * hw + p) * (3 * (size_t)C) + which * C + g * CB + v * 8, x);
+        store8(lq + which * TMAX * RS + f * RS + v * 8, x);
     }
     __syncthreads();
 
@@ -51,22 +51,23 @@ __global__ void __launch_bounds__(256) tattn_kernel(const h16* __restrict__ qkv,
         const bool act = it < items;
         const int hh = it >> 1, qi = (it & 1) * 16 + i16;    // head in group, query frame
         if (act) {
-            h16x8 qv[D / 8];
-            const h16* qrow = lq + qi * RS + hh * D;
+            float qv[D / 8][8];
+            const T* qrow = lq + qi * RS + hh * D;
 #pragma unroll
-            for (int c = 0; c < D / 8; ++c) qv[c] = *reinterpret_cast<const h16x8*>(qrow + c * 8);
+            for (int c = 0; c < D / 8; ++c) load8(qrow + c * 8, qv[c]);
             float s[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const h16* krow = lk + (jq * 8 + t) * RS + hh * D;
+                const T* krow = lk + (jq * 8 + t) * RS + hh * D;
                 float a = 0.f;
 #pragma unroll
                 for (int c = 0; c < D / 8; ++c) {
-                    const h16x8 kv = *reinterpret_cast<const h16x8*>(krow + c * 8);
+                    float kv[8];
+                    load8(krow + c * 8, kv);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a += (float)qv[c][e] * (float)kv[e];
+                    for (int e = 0; e < 8; ++e) a += qv[c][e] * kv[e];
                 }
-                s[t] = (jq * 8 + t < T) ? a * scale : -1e30f;
+                s[t] = (jq * 8 + t < Tn) ? a * scale : -1e30f;
             }
             float mx = s[0];
 #pragma unroll
@@ -86,27 +87,28 @@ __global__ void __launch_bounds__(256) tattn_kernel(const h16* __restrict__ qkv,
             for (int t = 0; t < 8; ++t) myp[i16 * 33 + jq * 8 + t] = s[t] * inv;
         }
         __syncthreads();
-        if (act && qi < T) {
+        if (act && qi < Tn) {
             constexpr int DQ = D / 4;                        // channels per lane
             float o[DQ];
 #pragma unroll
             for (int c = 0; c < DQ; ++c) o[c] = 0.f;
-            const h16* vcol = lv + hh * D + jq * DQ;
-            for (int j = 0; j < T; ++j) {
+            typedef T T2 __attribute__((ext_vector_type(2)));
+            const T* vcol = lv + hh * D + jq * DQ;
+            for (int j = 0; j < Tn; ++j) {
                 const float pj = myp[i16 * 33 + j];
-                const h16* vr = vcol + j * RS;
+                const T* vr = vcol + j * RS;
 #pragma unroll
                 for (int c = 0; c < DQ; c += 2) {
-                    const h16x2 vv = *reinterpret_cast<const h16x2*>(vr + c);
+                    const T2 vv = *reinterpret_cast<const T2*>(vr + c);
                     o[c] += pj * (float)vv[0];
                     o[c + 1] += pj * (float)vv[1];
                 }
             }
-            h16* op = out + ((size_t)qi * hw + p) * C + g * CB + hh * D + jq * DQ;
+            T* op = out + ((size_t)qi * hw + p) * C + g * CB + hh * D + jq * DQ;
 #pragma unroll
             for (int c = 0; c < DQ; c += 2) {
-                h16x2 ov = {(h16)o[c], (h16)o[c + 1]};
-                *reinterpret_cast<h16x2*>(op + c) = ov;
+                const T2 ov = {(T)o[c], (T)o[c + 1]};
+                *reinterpret_cast<T2*>(op + c) = ov;
             }
         }
         __syncthreads();
@@ -234,30 +236,42 @@ template <int D>
 int launch_tattn_mfma(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipStream_t s) {
     constexpr size_t smem = (size_t)4 * 2 * TMAX * (2 * D + (D == 64 ? 80 : 48));
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_mfma_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr_set = true;
-    }
+    static VdaKernelDeviceState dev_state;
+    if (vda_prepare_kernel(reinterpret_cast<const void*>(&tattn_mfma_kernel<D>), (int)smem, dev_state) < 0) return 2;
     hipLaunchKernelGGL((tattn_mfma_kernel<D>), dim3(hw, (heads + 3) / 4), dim3(256), smem, s, qkv, out, T, hw, C, heads);
     VDA_LAUNCH_CHECK();
     return 0;
 }
 
-template <int D>
-int launch_tattn(const h16* qkv, h16* out, int T, int hw, int C, int heads, hipStream_t s) {
+template <int D, typename T>
+int launch_tattn(const T* qkv, T* out, int Tn, int hw, int C, int heads, hipStream_t s) {
+    // head group: as many heads per workgroup as keep q, k, v of the group (3 x 32 rows) within 64 KiB of LDS
+    constexpr int max_cb = sizeof(T) == 2 ? 256 : 128;
     int hg = 1;
-    while (hg * 2 <= heads && hg * 2 * D <= 256) hg *= 2;
+    while (hg * 2 <= heads && hg * 2 * D <= max_cb) hg *= 2;
     const int CB = hg * D, RS = CB + 8;
-    const size_t smem = (size_t)3 * TMAX * RS * sizeof(h16) + 4 * 16 * 33 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((tattn_kernel<D>), dim3(hw, heads / hg), dim3(256), smem, s, qkv, out, T, hw, C, hg);
+    const size_t smem = (size_t)3 * TMAX * RS * sizeof(T) + 4 * 16 * 33 * sizeof(float);
+    static VdaKernelDeviceState dev_state;
+    if (vda_prepare_kernel(reinterpret_cast<const void*>(&tattn_kernel<D, T>), 64 * 1024, dev_state) < 0) return 2;
+    hipLaunchKernelGGL((tattn_kernel<D, T>), dim3(hw, heads / hg), dim3(256), smem, s, qkv, out, Tn, hw, C, hg);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T>
+int tattn_valu_dispatch(const T* q, T* o, int Tn, int hw, int C, int heads, hipStream_t s) {
+    switch (C / heads) {
+        case 8: return launch_tattn<8, T>(q, o, Tn, hw, C, heads, s);
+        case 16: return launch_tattn<16, T>(q, o, Tn, hw, C, heads, s);
+        case 24: return launch_tattn<24, T>(q, o, Tn, hw, C, heads, s);
+        case 32: return launch_tattn<32, T>(q, o, Tn, hw, C, heads, s);
+        case 48: return launch_tattn<48, T>(q, o, Tn, hw, C, heads, s);
+        case 64: return launch_tattn<64, T>(q, o, Tn, hw, C, heads, s);
+        case 128: return launch_tattn<128, T>(q, o, Tn, hw, C, heads, s);
+        default: break;
+    }
+    vda_set_error("vda_temporal_attention: unsupported head dim %d", C / heads);
+    return 1;
 }
 
 }  // namespace
@@ -285,16 +299,14 @@ extern "C" int vda_temporal_attention_f16(const void* qkv, void* out, int T, int
             default: break;
         }
     }
-    switch (C / heads) {
-        case 8: return launch_tattn<8>(q, o, T, hw, C, heads, s);
-        case 16: return launch_tattn<16>(q, o, T, hw, C, heads, s);
-        case 24: return launch_tattn<24>(q, o, T, hw, C, heads, s);
-        case 32: return launch_tattn<32>(q, o, T, hw, C, heads, s);
-        case 48: return launch_tattn<48>(q, o, T, hw, C, heads, s);
-        case 64: return launch_tattn<64>(q, o, T, hw, C, heads, s);
-        case 128: return launch_tattn<128>(q, o, T, hw, C, heads, s);
-        default: break;
-    }
-    vda_set_error("vda_temporal_attention: unsupported head dim %d", C / heads);
-    return 1;
+    return tattn_valu_dispatch<h16>(q, o, T, hw, C, heads, s);
+}
+
+// fp32-operand form (the reference's fp32=True path): the VALU kernel on fp32 q / k / v, fp32 out.
+extern "C" int vda_temporal_attention_f32(const float* qkv, float* out, int T, int hw, int C, int heads, vda_stream_t stream) {
+    VDA_REQUIRE(qkv && out, "vda_temporal_attention_f32: null pointer");
+    VDA_REQUIRE(T > 0 && T <= TMAX, "vda_temporal_attention_f32: T=%d must be in 1..%d", T, TMAX);
+    VDA_REQUIRE(hw > 0 && heads > 0 && (heads & (heads - 1)) == 0 && C % heads == 0, "vda_temporal_attention_f32: bad geometry C=%d heads=%d", C, heads);
+    VDA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && C % 8 == 0, "vda_temporal_attention_f32: alignment");
+    return tattn_valu_dispatch<float>(qkv, out, T, hw, C, heads, (hipStream_t)stream);
 }

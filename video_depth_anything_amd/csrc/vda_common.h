@@ -83,3 +83,57 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// 8 consecutive activations as floats, for kernels instantiated for both activation types (h16: the fp16-operand path,
+// float: the fp32-operand path). 16-byte accesses for h16, two for float.
+__device__ __forceinline__ void load8(const h16* p, float (&v)[8]) {
+    const h16x8 x = *reinterpret_cast<const h16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+}
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        v[e] = a[e];
+        v[4 + e] = b[e];
+    }
+}
+__device__ __forceinline__ void store8(h16* p, const float (&v)[8]) {
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)v[e];
+    *reinterpret_cast<h16x8*>(p) = o;
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a process that drives several GPUs (model.to('cuda:1'))
+// must set it on each one. `done` is the caller's static per-kernel bit mask of devices already configured; returns the
+// number of CUs of the current device rounded down to a multiple of 8 (persistent grids), or < 0 on error.
+struct VdaKernelDeviceState {
+    unsigned long long done = 0;
+    int num_cu[64] = {};
+};
+inline int vda_prepare_kernel(const void* fn, int dyn_lds_bytes, VdaKernelDeviceState& st) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = dev & 63;
+    if (!((st.done >> slot) & 1ull)) {
+        if (dyn_lds_bytes > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn_lds_bytes);
+            if (e != hipSuccess) {
+                vda_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return -1;
+            }
+        }
+        int cu = 0;
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cu < 8) cu = 8;
+        st.num_cu[slot] = cu & ~7;
+        st.done |= 1ull << slot;
+    }
+    return st.num_cu[slot];
+}

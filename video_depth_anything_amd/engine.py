@@ -15,23 +15,26 @@ convs with no transpose):
   head  fp16 NHWC [BT, h, w, Cpad]; channel counts padded to multiples of 64 at pack time
         (ViT-S: 48->64, 96->128, F/2=32->64) so every GEMM K is a multiple of the 64-wide K step
   temporal residual stream fp32 [BT*hw, C]
-Precision map: fp16 operands, fp32 accumulate; LayerNorm/GroupNorm/softmax statistics fp32;
-encoder and temporal residual streams fp32; final 32->1 projection reads fp16, writes fp32.
+Precision map (default, the reference's autocast path): fp16 operands, fp32 accumulate; LayerNorm/GroupNorm/softmax
+statistics fp32; encoder and temporal residual streams fp32; final 32->1 projection reads fp16, writes fp32.
+`forward(x, fp32=True)` (the reference's fp32=True, video_depth.py:203-205): every buffer above is fp32 and every product
+runs on fp32-input MFMA (exact fp32) through the *_f32 entry points; same launch sequence, the depth tail unfused.
+
+This Python orchestration is the cross-check of the C++ one behind `vda_forward` (csrc/host.hip), which is what
+`VideoDepthAnything` runs: both issue the same launches on the same layouts, so their outputs are bit-identical
+(tests/test_handle_gpu.py). It also exposes every intermediate stage for the golden tests.
 
 Algebraic rewrite (exact in real arithmetic): FeatureFusionBlock's `out_conv(bilinear(x))`
 (util/blocks.py:156-160) runs as `bilinear(out_conv(x))`: a 1x1 conv and an align_corners
 bilinear resize commute (interpolation weights sum to 1, so the bias commutes too), which
 cuts the 1x1 conv's FLOPs 4x.
 """
-import math
 from typing import Dict, List
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib, ops
-from .config import (ENC_LN_EPS, GN_EPS, GN_GROUPS, INTERP_OFFSET, PATCH, POS_GRID, TEMPORAL_HEADS, TMP_LN_EPS,
-                     ModelConfig)
+from .config import ENC_LN_EPS, GN_EPS, GN_GROUPS, PATCH, POS_GRID, TEMPORAL_HEADS, TMP_LN_EPS, ModelConfig
 from .weights import check_state_dict, temporal_channels
 
 F16, F32 = torch.float16, torch.float32
@@ -48,24 +51,41 @@ class Engine:
             raise RuntimeError("video_depth_anything_amd needs an MI355X (HIP device); there is no CPU path")
         self.cfg = cfg
         self.device = torch.device(device)
-        self.w: Dict[str, torch.Tensor] = {}
-        self._buf: Dict[str, torch.Tensor] = {}
+        self.w: Dict[str, torch.Tensor] = {}        # the pack of the precision in use (set by forward)
+        self.act = F16                              # activation / operand dtype in use
+        self._packs: Dict[torch.dtype, Dict[str, torch.Tensor]] = {}
+        self._buf: Dict[tuple, torch.Tensor] = {}
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
         self.loaded = False
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, strict=True):
-        cfg = self.cfg
-        check_state_dict(cfg, sd, strict)
+        check_state_dict(self.cfg, sd, strict)
+        self._sd = sd
+        self._packs.clear()
+        self._pos_cache.clear()
+        with torch.cuda.device(self.device):
+            self._pos_embed_dev = sd["pretrained.pos_embed"].detach().to(self.device, F32).reshape(-1, self.cfg.embed_dim).contiguous()
+            self.w = self._pack(F16)
+        self.loaded = True
+
+    def _pack(self, dt):
+        """Kernel layouts of every weight for operand dtype `dt` (fp16, or fp32 on the first fp32 forward)."""
+        if dt in self._packs:
+            return self._packs[dt]
+        cfg, sd = self.cfg, self._sd
         dv = self.device
-        w = self.w
+        w: Dict[str, torch.Tensor] = {}
 
         def f32(name):
             return sd[name].detach().to(dv, F32).contiguous()
 
         def lin(name, n_pad=None, k_pad=None):
             t = sd[name].detach().to(dv, F32)
-            return ops.pack_linear(t.reshape(t.shape[0], -1), n_pad, k_pad)
+            return ops.pack_linear(t.reshape(t.shape[0], -1), n_pad, k_pad, dtype=dt)
+
+        def conv(name, cout_pad=None, cin_pad=None):
+            return ops.pack_conv3x3(sd[name].detach().to(dv, F32), cout_pad, cin_pad, dtype=dt)
 
         def padvec(name, n):
             v = torch.zeros(n, dtype=F32, device=dv)
@@ -81,8 +101,6 @@ class Engine:
         w["patch.w"] = lin(p + "patch_embed.proj.weight", k_pad=KPATCH)
         w["patch.b"] = f32(p + "patch_embed.proj.bias")
         w["cls"] = f32(p + "cls_token").reshape(-1)
-        self._pos_embed_host = sd[p + "pos_embed"].detach().float().cpu()
-        self._pos_cache.clear()
         for i in range(cfg.depth):
             b = f"{p}blocks.{i}."
             for n in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "attn.qkv.bias", "attn.proj.bias",
@@ -98,22 +116,22 @@ class Engine:
             w[f"proj{i}.b"] = padvec(f"{h}projects.{i}.bias", ocp[i])
         for i in (0, 1):
             w[f"resize{i}.w"], w[f"resize{i}.b"] = ops.pack_convt(
-                sd[f"{h}resize_layers.{i}.weight"].detach().to(dv, F32), sd[f"{h}resize_layers.{i}.bias"].detach().to(dv, F32), ocp[i])
-        w["resize3.w"] = ops.pack_conv3x3(sd[h + "resize_layers.3.weight"].detach().to(dv, F32), ocp[3], ocp[3])
+                sd[f"{h}resize_layers.{i}.weight"].detach().to(dv, F32), sd[f"{h}resize_layers.{i}.bias"].detach().to(dv, F32), ocp[i], dtype=dt)
+        w["resize3.w"] = conv(h + "resize_layers.3.weight", ocp[3], ocp[3])
         w["resize3.b"] = padvec(h + "resize_layers.3.bias", ocp[3])
         sc = h + "scratch."
         for i in range(4):
-            w[f"rn{i + 1}.w"] = ops.pack_conv3x3(sd[f"{sc}layer{i + 1}_rn.weight"].detach().to(dv, F32), Fe, ocp[i])
+            w[f"rn{i + 1}.w"] = conv(f"{sc}layer{i + 1}_rn.weight", Fe, ocp[i])
         for i in (1, 2, 3, 4):
             r = f"{sc}refinenet{i}."
             w[f"ref{i}.out.w"], w[f"ref{i}.out.b"] = lin(r + "out_conv.weight"), f32(r + "out_conv.bias")
             for u in (1, 2):
                 for c in (1, 2):
-                    w[f"ref{i}.rcu{u}.c{c}.w"] = ops.pack_conv3x3(sd[f"{r}resConfUnit{u}.conv{c}.weight"].detach().to(dv, F32))
+                    w[f"ref{i}.rcu{u}.c{c}.w"] = conv(f"{r}resConfUnit{u}.conv{c}.weight")
                     w[f"ref{i}.rcu{u}.c{c}.b"] = f32(f"{r}resConfUnit{u}.conv{c}.bias")
-        w["oc1.w"] = ops.pack_conv3x3(sd[sc + "output_conv1.weight"].detach().to(dv, F32), Fhp, Fe)
+        w["oc1.w"] = conv(sc + "output_conv1.weight", Fhp, Fe)
         w["oc1.b"] = padvec(sc + "output_conv1.bias", Fhp)
-        w["oc2.w"] = ops.pack_conv3x3(sd[sc + "output_conv2.0.weight"].detach().to(dv, F32), 32, Fhp)
+        w["oc2.w"] = conv(sc + "output_conv2.0.weight", 32, Fhp)
         w["oc2.b"] = f32(sc + "output_conv2.0.bias")
         w["oc3.w"] = f32(sc + "output_conv2.2.weight").reshape(-1)
         self.oc3_bias = float(sd[sc + "output_conv2.2.bias"].reshape(-1)[0])
@@ -127,20 +145,21 @@ class Engine:
             for a in (0, 1):
                 ab = f"{tb}attention_blocks.{a}."
                 qkv = torch.cat([sd[ab + "to_q.weight"], sd[ab + "to_k.weight"], sd[ab + "to_v.weight"]], dim=0)
-                w[f"{k}a{a}.qkv.w"] = ops.pack_linear(qkv.detach().to(dv, F32))
+                w[f"{k}a{a}.qkv.w"] = ops.pack_linear(qkv.detach().to(dv, F32), dtype=dt)
                 w[f"{k}a{a}.out.w"], w[f"{k}a{a}.out.b"] = lin(ab + "to_out.0.weight"), f32(ab + "to_out.0.bias")
                 w[f"{k}a{a}.pe"] = f32(ab + "pos_encoder.pe").reshape(-1, Cc)
                 w[f"{k}a{a}.ln.w"], w[f"{k}a{a}.ln.b"] = f32(f"{tb}norms.{a}.weight"), f32(f"{tb}norms.{a}.bias")
             w[k + "ffln.w"], w[k + "ffln.b"] = f32(tb + "ff_norm.weight"), f32(tb + "ff_norm.bias")
-            gw, gb = ops.pack_geglu(sd[tb + "ff.net.0.proj.weight"].detach().to(dv, F32), sd[tb + "ff.net.0.proj.bias"].detach().to(dv, F32))
+            gw, gb = ops.pack_geglu(sd[tb + "ff.net.0.proj.weight"].detach().to(dv, F32), sd[tb + "ff.net.0.proj.bias"].detach().to(dv, F32), dtype=dt)
             w[k + "ff1.w"], w[k + "ff1.b"] = gw, gb
             w[k + "ff2.w"], w[k + "ff2.b"] = lin(tb + "ff.net.2.weight"), f32(tb + "ff.net.2.bias")
-        self.loaded = True
+        self._packs[dt] = w
+        return w
 
     # ------------------------------------------------------------------ helpers
     def buf(self, name, shape, dtype, zero=False):
         """Named workspace, allocated once per shape (no allocation in steady state)."""
-        key = name
+        key = (name, dtype)
         t = self._buf.get(key)
         n = 1
         for s in shape:
@@ -151,23 +170,20 @@ class Engine:
         return t[:n].view(*shape)
 
     def pos_embed(self, H, W):
-        """dinov2.py:179-210. Resampling (non-518x518 inputs only) is weight preprocessing: done once per
-        input shape on the host with the same fp32 bicubic call the reference makes, then cached."""
+        """dinov2.py:179-210. The stored grid when the input has 37 x 37 patches and is square; otherwise the grid is
+        resampled on the device (vda_pos_embed_resample_f32: the reference's bicubic with its 0.1 offset), once per shape."""
         key = (H, W)
         t = self._pos_cache.get(key)
         if t is not None:
             return t
-        pe = self._pos_embed_host
-        n = pe.shape[1] - 1
+        pe = self._pos_embed_dev
+        n = pe.shape[0] - 1
         ph, pw = H // PATCH, W // PATCH
-        if not (ph * pw == n and H == W):
-            g, dim = int(math.sqrt(n)), pe.shape[-1]
-            sy, sx = float(ph + INTERP_OFFSET) / math.sqrt(n), float(pw + INTERP_OFFSET) / math.sqrt(n)
-            grid = pe[:, 1:].reshape(1, g, g, dim).permute(0, 3, 1, 2)
-            grid = F.interpolate(grid, scale_factor=(sy, sx), mode="bicubic", antialias=False)
-            assert grid.shape[-2] == ph and grid.shape[-1] == pw
-            pe = torch.cat((pe[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)), dim=1)
-        t = pe[0].to(self.device, F32).contiguous()
+        if ph * pw == n and H == W:
+            t = pe
+        else:
+            t = torch.empty(1 + ph * pw, pe.shape[1], dtype=F32, device=self.device)
+            ops.pos_embed_resample(pe, t, POS_GRID, ph, pw, pe.shape[1])
         self._pos_cache[key] = t
         return t
 
@@ -185,13 +201,13 @@ class Engine:
         rows = BT * hw
         chunks = max(1, min(16, (hw + 31) // 32))
         part = self.buf("gn_partial", (BT * chunks * GN_GROUPS * 2,), F32)
-        g = self.buf("tm_g", (rows, Cc), F16)
+        g = self.buf("tm_g", (rows, Cc), self.act)
         ops.groupnorm(x, g, w[k + "gn.w"], w[k + "gn.b"], GN_EPS, BT, hw, Cc, GN_GROUPS, part, chunks)
         hs = self.buf("tm_hs", (rows, Cc), F32)
         ops.gemm(g, w[k + "in.w"], hs, _lib.EPI_BIAS_F32, M=rows, N=Cc, K=Cc, bias=w[k + "in.b"])
-        n = self.buf("tm_n", (rows, Cc), F16)
-        qkv = self.buf("tm_qkv", (rows, 3 * Cc), F16)
-        ao = self.buf("tm_ao", (rows, Cc), F16)
+        n = self.buf("tm_n", (rows, Cc), self.act)
+        qkv = self.buf("tm_qkv", (rows, 3 * Cc), self.act)
+        ao = self.buf("tm_ao", (rows, Cc), self.act)
         for a in (0, 1):
             ops.layernorm(hs, n, w[f"{k}a{a}.ln.w"], w[f"{k}a{a}.ln.b"], TMP_LN_EPS, rows, Cc,
                           pe=w[f"{k}a{a}.pe"], pe_rows_per_step=hw, pe_steps=T)
@@ -201,11 +217,11 @@ class Engine:
                 ops.temporal_attention(qkv[r0:r0 + T * hw], ao[r0:r0 + T * hw], T, hw, Cc, TEMPORAL_HEADS)
             ops.gemm(ao, w[f"{k}a{a}.out.w"], hs, _lib.EPI_SCALE_RES_F32, M=rows, N=Cc, K=Cc, bias=w[f"{k}a{a}.out.b"], res=hs)
         ops.layernorm(hs, n, w[k + "ffln.w"], w[k + "ffln.b"], TMP_LN_EPS, rows, Cc)
-        gg = self.buf("tm_gg", (rows, 4 * Cc), F16)
+        gg = self.buf("tm_gg", (rows, 4 * Cc), self.act)
         ops.gemm(n, w[k + "ff1.w"], gg, _lib.EPI_GEGLU_F16, M=rows, N=8 * Cc, K=Cc, ldc=4 * Cc, bias=w[k + "ff1.b"])
-        hh = self.buf("tm_hh", (rows, Cc), F16)
+        hh = self.buf("tm_hh", (rows, Cc), self.act)
         ops.gemm(gg, w[k + "ff2.w"], hh, _lib.EPI_SCALE_RES_F32_H, M=rows, N=Cc, K=4 * Cc, bias=w[k + "ff2.b"], res=hs)
-        out = self.buf(tag, (rows, Cc), F16)
+        out = self.buf(tag, (rows, Cc), self.act)
         ops.gemm(hh, w[k + "out.w"], out, _lib.EPI_RES_F16, M=rows, N=Cc, K=Cc, bias=w[k + "out.b"], res=x)
         return out
 
@@ -213,7 +229,7 @@ class Engine:
     def rcu(self, i, u, x, out, B, H, W, Fe, res2=None):
         """util/blocks.py:68-91: conv2(relu(conv1(relu(x)))) + x (+ res2 fused for the block's skip add)."""
         w = self.w
-        y = self.buf("rcu_y", (B * H * W, Fe), F16)
+        y = self.buf("rcu_y", (B * H * W, Fe), self.act)
         self.conv3x3(x, f"ref{i}.rcu{u}.c1.w", y, B, H, W, Fe, Fe, _lib.EPI_BIAS_RELU_F16, bias=w[f"ref{i}.rcu{u}.c1.b"], relu_in=True)
         self.conv3x3(y, f"ref{i}.rcu{u}.c2.w", out, B, H, W, Fe, Fe, _lib.EPI_RES_F16, bias=w[f"ref{i}.rcu{u}.c2.b"], res=x, res2=res2)
 
@@ -223,22 +239,28 @@ class Engine:
         rows = B * H * W
         s = x0
         if x1 is not None:
-            s = self.buf("fus_s", (rows, Fe), F16)
+            s = self.buf("fus_s", (rows, Fe), self.act)
             self.rcu(i, 1, x1, s, B, H, W, Fe, res2=x0)
-        r = self.buf("fus_r", (rows, Fe), F16)
+        r = self.buf("fus_r", (rows, Fe), self.act)
         self.rcu(i, 2, s, r, B, H, W, Fe)
-        c = self.buf("fus_c", (rows, Fe), F16)
+        c = self.buf("fus_c", (rows, Fe), self.act)
         ops.gemm(r, w[f"ref{i}.out.w"], c, _lib.EPI_BIAS_F16, M=rows, N=Fe, K=Fe, bias=w[f"ref{i}.out.b"])
-        out = self.buf(tag, (B * Ho * Wo, Fe), F16)
+        out = self.buf(tag, (B * Ho * Wo, Fe), self.act)
         ops.bilinear_nhwc(c, out, B, H, W, Ho, Wo, Fe)
         return out
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def forward(self, x, taps_out: List[torch.Tensor] = None, stages: dict = None):
-        """x: fp32 cuda [B,T,3,H,W] -> depth fp32 [B,T,H,W]."""
+    def forward(self, x, taps_out: List[torch.Tensor] = None, stages: dict = None, fp32: bool = False):
+        """x: fp32 cuda [B,T,3,H,W] -> depth fp32 [B,T,H,W]. fp32=True: fp32 operands and activations throughout."""
         if not self.loaded:
             raise RuntimeError("load_state_dict() first")
+        with torch.cuda.device(self.device):
+            return self._forward(x, taps_out, stages, fp32)
+
+    def _forward(self, x, taps_out, stages, fp32):
+        self.act = F32 if fp32 else F16
+        self.w = self._pack(self.act)
         cfg, w = self.cfg, self.w
         if x.dim() != 5 or x.shape[2] != 3:
             raise ValueError(f"expected [B,T,3,H,W], got {tuple(x.shape)}")
@@ -254,16 +276,16 @@ class Engine:
         rows = BT * Nt
 
         # ---- encoder (dinov2.py:212-219, block.py:105-106)
-        a0 = self.buf("a0", (BT * P, KPATCH), F16, zero=True)      # pad columns stay zero for ever
+        a0 = self.buf("a0", (BT * P, KPATCH), self.act, zero=True)      # pad columns stay zero for ever
         ops.patchify(x, a0, BT, H, W, KPATCH)
         tok = self.buf("tok", (rows, D), F32)
         pos = self.pos_embed(H, W)
         ops.gemm(a0, w["patch.w"], tok, _lib.EPI_PATCH_F32, M=BT * P, N=D, K=KPATCH, bias=w["patch.b"], pos=pos, P=P)
         ops.cls_rows(tok, w["cls"], pos, BT, P, D)
-        xn = self.buf("xn", (rows, D), F16)
-        qkv = self.buf("qkv", (rows, 3 * D), F16)
-        ao = self.buf("ao", (rows, D), F16)
-        hid = self.buf("hid", (rows, 4 * D), F16)
+        xn = self.buf("xn", (rows, D), self.act)
+        qkv = self.buf("qkv", (rows, 3 * D), self.act)
+        ao = self.buf("ao", (rows, D), self.act)
+        hid = self.buf("hid", (rows, 4 * D), self.act)
         taps = []
         for i in range(cfg.depth):
             k = f"b{i}."
@@ -277,7 +299,7 @@ class Engine:
             ops.gemm(hid, w[k + "mlp.fc2.weight"], tok, _lib.EPI_SCALE_RES_F32, M=rows, N=D, K=4 * D, bias=w[k + "mlp.fc2.bias"],
                      gamma=w[k + "ls2.gamma"], res=tok)
             if i in cfg.taps:
-                tp = self.buf(f"tap{len(taps)}", (BT * P, D), F16)
+                tp = self.buf(f"tap{len(taps)}", (BT * P, D), self.act)
                 ops.layernorm(tok, tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
                 taps.append(tp)
         if taps_out is not None:
@@ -287,21 +309,21 @@ class Engine:
         ocp, Fe, Fhp = self.ocp, cfg.features, self.Fhp
         h1, w1, h2, w2 = 4 * ph, 4 * pw, 2 * ph, 2 * pw
         h4, w4 = (ph - 1) // 2 + 1, (pw - 1) // 2 + 1
-        t0 = self.buf("t0", (BT * P, ocp[0]), F16)
+        t0 = self.buf("t0", (BT * P, ocp[0]), self.act)
         ops.gemm(taps[0], w["proj0.w"], t0, _lib.EPI_BIAS_F16, M=BT * P, N=ocp[0], K=D, bias=w["proj0.b"])
-        l1 = self.buf("l1", (BT * h1 * w1, ocp[0]), F16)
+        l1 = self.buf("l1", (BT * h1 * w1, ocp[0]), self.act)
         ops.gemm(t0, w["resize0.w"], l1, _lib.EPI_CONVT_F16, M=BT * P, N=16 * ocp[0], K=ocp[0], ldc=ocp[0], bias=w["resize0.b"],
                  convt=(4, ph, pw, ocp[0]))
-        t1 = self.buf("t1", (BT * P, ocp[1]), F16)
+        t1 = self.buf("t1", (BT * P, ocp[1]), self.act)
         ops.gemm(taps[1], w["proj1.w"], t1, _lib.EPI_BIAS_F16, M=BT * P, N=ocp[1], K=D, bias=w["proj1.b"])
-        l2 = self.buf("l2", (BT * h2 * w2, ocp[1]), F16)
+        l2 = self.buf("l2", (BT * h2 * w2, ocp[1]), self.act)
         ops.gemm(t1, w["resize1.w"], l2, _lib.EPI_CONVT_F16, M=BT * P, N=4 * ocp[1], K=ocp[1], ldc=ocp[1], bias=w["resize1.b"],
                  convt=(2, ph, pw, ocp[1]))
-        l3 = self.buf("l3", (BT * P, ocp[2]), F16)
+        l3 = self.buf("l3", (BT * P, ocp[2]), self.act)
         ops.gemm(taps[2], w["proj2.w"], l3, _lib.EPI_BIAS_F16, M=BT * P, N=ocp[2], K=D, bias=w["proj2.b"])
-        t3 = self.buf("t3", (BT * P, ocp[3]), F16)
+        t3 = self.buf("t3", (BT * P, ocp[3]), self.act)
         ops.gemm(taps[3], w["proj3.w"], t3, _lib.EPI_BIAS_F16, M=BT * P, N=ocp[3], K=D, bias=w["proj3.b"])
-        l4 = self.buf("l4", (BT * h4 * w4, ocp[3]), F16)
+        l4 = self.buf("l4", (BT * h4 * w4, ocp[3]), self.act)
         self.conv3x3(t3, "resize3.w", l4, BT, ph, pw, ocp[3], ocp[3], _lib.EPI_BIAS_F16, stride=2, bias=w["resize3.b"])
 
         # ---- temporal modules on layer_3 / layer_4 (dpt_temporal.py:75-76)
@@ -309,13 +331,13 @@ class Engine:
         l4 = self.temporal(1, l4, B, T, h4 * w4, ocp[3], "l4t")
 
         # ---- layer_rn (no bias) and the fusion pyramid (dpt_temporal.py:78-91)
-        l1r = self.buf("l1r", (BT * h1 * w1, Fe), F16)
+        l1r = self.buf("l1r", (BT * h1 * w1, Fe), self.act)
         self.conv3x3(l1, "rn1.w", l1r, BT, h1, w1, ocp[0], Fe, _lib.EPI_BIAS_F16)
-        l2r = self.buf("l2r", (BT * h2 * w2, Fe), F16)
+        l2r = self.buf("l2r", (BT * h2 * w2, Fe), self.act)
         self.conv3x3(l2, "rn2.w", l2r, BT, h2, w2, ocp[1], Fe, _lib.EPI_BIAS_F16)
-        l3r = self.buf("l3r", (BT * P, Fe), F16)
+        l3r = self.buf("l3r", (BT * P, Fe), self.act)
         self.conv3x3(l3, "rn3.w", l3r, BT, ph, pw, ocp[2], Fe, _lib.EPI_BIAS_F16)
-        l4r = self.buf("l4r", (BT * h4 * w4, Fe), F16)
+        l4r = self.buf("l4r", (BT * h4 * w4, Fe), self.act)
         self.conv3x3(l4, "rn4.w", l4r, BT, h4, w4, ocp[3], Fe, _lib.EPI_BIAS_F16)
 
         p4 = self.fusion(4, l4r, None, BT, h4, w4, ph, pw, Fe, "p4")
@@ -327,12 +349,20 @@ class Engine:
 
         # ---- output convs (dpt.py:117-124, dpt_temporal.py:93-100)
         hh, ww = 2 * h1, 2 * w1
-        o1 = self.buf("o1", (BT * hh * ww, Fhp), F16)
+        o1 = self.buf("o1", (BT * hh * ww, Fhp), self.act)
         self.conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, _lib.EPI_BIAS_F16, bias=w["oc1.b"])
         # bilinear to (H,W) + output_conv2 (3x3 -> ReLU -> 1x1 -> ReLU) in one kernel: the 518^2 x F/2 upsampled tensor is
         # never materialised (dpt_temporal.py:94-100)
         depth = torch.empty(B, T, H, W, dtype=F32, device=self.device)
-        ops.depth_tail(o1, w["oc2.w"], w["oc2.b"], w["oc3.w"], self.oc3_bias, depth, BT, hh, ww, H, W, Fhp)
+        if not fp32:
+            ops.depth_tail(o1, w["oc2.w"], w["oc2.b"], w["oc3.w"], self.oc3_bias, depth, BT, hh, ww, H, W, Fhp)
+        else:
+            # fp32 operands: the same three steps unfused (speed is secondary on this path)
+            up = self.buf("tail_up", (BT * H * W, Fhp), F32)
+            ops.bilinear_nhwc(o1, up, BT, hh, ww, H, W, Fhp)
+            c2 = self.buf("tail_c2", (BT * H * W, 32), F32)
+            self.conv3x3(up, "oc2.w", c2, BT, H, W, Fhp, 32, _lib.EPI_BIAS_RELU_F16, bias=w["oc2.b"])
+            ops.head_out(c2, w["oc3.w"], self.oc3_bias, depth, BT * H * W, 32)
         # video_depth.py:162-163: bilinear to (H,W) is the identity here (H == 14*ph) and the ReLU is idempotent.
         if stages is not None:
             stages.update(layer_1=(l1, h1, w1, ocp[0]), layer_2=(l2, h2, w2, ocp[1]), layer_3=(l3, ph, pw, ocp[2]),

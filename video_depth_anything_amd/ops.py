@@ -3,6 +3,9 @@
 torch is used for device memory and the current HIP stream only; every op here
 is one call into libvda_hip.so and nothing else. Shapes are validated twice:
 here (tensor metadata the C side cannot see) and in the library (geometry).
+
+Two operand precisions share these wrappers, selected by the dtype of the activation tensors handed in: fp16
+(the *_f16 entry points: the reference's autocast path) and fp32 (the *_f32 twins: its fp32=True path).
 """
 import ctypes as C
 
@@ -30,8 +33,17 @@ def check(rc, what=""):
 F16, F32 = torch.float16, torch.float32
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t=None):
+    """The current stream of the device the operands live on (NOT of whichever device happens to be current)."""
+    dev = t.device if t is not None else None
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _act(t, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype not in (F16, F32) or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous cuda fp16 / fp32 activation, got {t.dtype} {t.device} contiguous={t.is_contiguous()}")
 
 
 def _p(t):
@@ -73,7 +85,8 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
          relu_in=False, conv=None, P=0, convt=None):
     """out = epilogue(A[M,K] W[N,K]^T). conv = (B,H,W,Cin,Ho,Wo,stride) switches A to the
     implicit 3x3 window of an NHWC tensor; convt = (k, h, w, Cout) for VDA_EPI_CONVT_F16."""
-    _req(A, F16, "A"), _req(W, F16, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
+    _act(A, "A"), _req(W, A.dtype, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
+    fn, fname = (lib.vda_gemm_f32, "vda_gemm_f32") if A.dtype == F32 else (lib.vda_gemm_f16, "vda_gemm_f16")
     a = GemmArgs()
     a.A, a.W, a.bias, a.out = _p(A), _p(W), _p(bias), _p(out)
     a.res, a.res2, a.gamma, a.pos = _p(res), _p(res2), _p(gamma), _p(pos)
@@ -93,8 +106,7 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
         raise ValueError("W smaller than N*K")
     prof = PROFILE
     if prof is None:
-        check(lib.vda_gemm_f16(C.byref(a), _stream()),
-              f"vda_gemm_f16 M={M} N={N} K={K} epi={epi} conv={conv} lda={a.lda} ldc={a.ldc}" if _TRACE else "vda_gemm_f16")
+        check(fn(C.byref(a), _stream(A)), f"{fname} M={M} N={N} K={K} epi={epi} conv={conv} lda={a.lda} ldc={a.ldc}" if _TRACE else fname)
         return
     key = (M, N, K, epi, a.a_mode)
     n = prof.seen.get(key, 0)
@@ -103,8 +115,8 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.vda_gemm_f16(C.byref(a), _stream()), "vda_gemm_f16")
-    name = lib.vda_gemm_last_kernel().decode()
+    check(fn(C.byref(a), _stream(A)), fname)
+    name = lib.vda_gemm_last_kernel().decode() if A.dtype == F16 else "gemm_f32_kernel"
     tot = prof.launches.setdefault(name, [0, 0.0])
     tot[0] += 1
     tot[1] += 2.0 * M * N * K
@@ -114,56 +126,69 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
 
 
 def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
-    _req(x, F32, "x"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(pe, F32, "pe")
-    check(lib.vda_layernorm_f32_f16(_p(x), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _p(pe), pe_rows_per_step,
-                                    pe_steps, _stream()), "vda_layernorm_f32_f16")
+    _req(x, F32, "x"), _act(out, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(pe, F32, "pe")
+    fn = lib.vda_layernorm_f32_f32 if out.dtype == F32 else lib.vda_layernorm_f32_f16
+    check(fn(_p(x), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _p(pe), pe_rows_per_step, pe_steps, _stream(x)), "vda_layernorm")
 
 
 def groupnorm(x, out, w, b, eps, frames, hw, Cc, groups, partial, chunks):
-    _req(x, F16, "x"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(partial, F32, "partial")
+    _act(x, "x"), _req(out, x.dtype, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(partial, F32, "partial")
     if partial.numel() < frames * chunks * groups * 2:
         raise ValueError("groupnorm workspace too small")
-    check(lib.vda_groupnorm_nhwc_f16(_p(x), _p(out), _p(w), _p(b), eps, frames, hw, Cc, groups, _p(partial), chunks,
-                                     _stream()), "vda_groupnorm_nhwc_f16")
+    fn = lib.vda_groupnorm_nhwc_f32 if x.dtype == F32 else lib.vda_groupnorm_nhwc_f16
+    check(fn(_p(x), _p(out), _p(w), _p(b), eps, frames, hw, Cc, groups, _p(partial), chunks, _stream(x)), "vda_groupnorm_nhwc")
 
 
 def attention(qkv, out, B, N, heads):
-    _req(qkv, F16, "qkv"), _req(out, F16, "out")
+    _act(qkv, "qkv"), _req(out, qkv.dtype, "out")
     if qkv.numel() < B * N * 3 * heads * 64 or out.numel() < B * N * heads * 64:
         raise ValueError("attention buffers too small")
-    check(lib.vda_attention_f16(_p(qkv), _p(out), B, N, heads, _stream()), "vda_attention_f16")
+    fn = lib.vda_attention_f32 if qkv.dtype == F32 else lib.vda_attention_f16
+    check(fn(_p(qkv), _p(out), B, N, heads, _stream(qkv)), "vda_attention")
 
 
 def temporal_attention(qkv, out, T, hw, Cc, heads=8):
-    _req(qkv, F16, "qkv"), _req(out, F16, "out")
+    _act(qkv, "qkv"), _req(out, qkv.dtype, "out")
     if qkv.numel() < T * hw * 3 * Cc or out.numel() < T * hw * Cc:
         raise ValueError("temporal attention buffers too small")
-    check(lib.vda_temporal_attention_f16(_p(qkv), _p(out), T, hw, Cc, heads, _stream()), "vda_temporal_attention_f16")
+    fn = lib.vda_temporal_attention_f32 if qkv.dtype == F32 else lib.vda_temporal_attention_f16
+    check(fn(_p(qkv), _p(out), T, hw, Cc, heads, _stream(qkv)), "vda_temporal_attention")
 
 
 def bilinear_nhwc(x, out, B, h, w, H, W, Cc, add=None):
-    _req(x, F16, "x"), _req(out, F16, "out"), _req(add, F16, "add")
-    check(lib.vda_bilinear_nhwc_f16(_p(x), _p(out), _p(add), B, h, w, H, W, Cc, _stream()), "vda_bilinear_nhwc_f16")
+    _act(x, "x"), _req(out, x.dtype, "out"), _req(add, x.dtype, "add")
+    fn = lib.vda_bilinear_nhwc_f32 if x.dtype == F32 else lib.vda_bilinear_nhwc_f16
+    check(fn(_p(x), _p(out), _p(add), B, h, w, H, W, Cc, _stream(x)), "vda_bilinear_nhwc")
 
 
 def bilinear_plane(x, out, B, h, w, H, W, relu=False):
     _req(x, F32, "x"), _req(out, F32, "out")
-    check(lib.vda_bilinear_plane_f32(_p(x), _p(out), B, h, w, H, W, 1 if relu else 0, _stream()), "vda_bilinear_plane_f32")
+    check(lib.vda_bilinear_plane_f32(_p(x), _p(out), B, h, w, H, W, 1 if relu else 0, _stream(x)), "vda_bilinear_plane_f32")
 
 
 def patchify(x, out, B, H, W, Kpad):
-    _req(x, F32, "x"), _req(out, F16, "out")
-    check(lib.vda_patchify_f32_f16(_p(x), _p(out), B, H, W, Kpad, _stream()), "vda_patchify_f32_f16")
+    _req(x, F32, "x"), _act(out, "out")
+    fn = lib.vda_patchify_f32_f32 if out.dtype == F32 else lib.vda_patchify_f32_f16
+    check(fn(_p(x), _p(out), B, H, W, Kpad, _stream(x)), "vda_patchify")
+
+
+def pos_embed_resample(pe, out, g, ph, pw, D):
+    """dinov2.py:185-210: pe fp32 [1 + g*g, D] -> out fp32 [1 + ph*pw, D]."""
+    _req(pe, F32, "pe"), _req(out, F32, "out")
+    if pe.numel() < (1 + g * g) * D or out.numel() < (1 + ph * pw) * D:
+        raise ValueError("pos_embed_resample buffers too small")
+    check(lib.vda_pos_embed_resample_f32(_p(pe), _p(out), g, ph, pw, D, _stream(pe)), "vda_pos_embed_resample_f32")
 
 
 def cls_rows(tok, cls, pos, B, P, D):
     _req(tok, F32, "tok"), _req(cls, F32, "cls"), _req(pos, F32, "pos")
-    check(lib.vda_cls_rows_f32(_p(tok), _p(cls), _p(pos), B, P, D, _stream()), "vda_cls_rows_f32")
+    check(lib.vda_cls_rows_f32(_p(tok), _p(cls), _p(pos), B, P, D, _stream(tok)), "vda_cls_rows_f32")
 
 
 def head_out(x, w, bias, out, rows, Cpad):
-    _req(x, F16, "x"), _req(w, F32, "w"), _req(out, F32, "out")
-    check(lib.vda_head_out_f16_f32(_p(x), _p(w), float(bias), _p(out), rows, Cpad, _stream()), "vda_head_out_f16_f32")
+    _act(x, "x"), _req(w, F32, "w"), _req(out, F32, "out")
+    fn = lib.vda_head_out_f32_f32 if x.dtype == F32 else lib.vda_head_out_f16_f32
+    check(fn(_p(x), _p(w), float(bias), _p(out), rows, Cpad, _stream(x)), "vda_head_out")
 
 
 def depth_tail(x, w2, b2, w3, b3, out, B, h, w, H, W, Cc):
@@ -172,19 +197,28 @@ def depth_tail(x, w2, b2, w3, b3, out, B, h, w, H, W, Cc):
     if x.numel() < B * h * w * Cc or out.numel() < B * H * W or w2.numel() < 32 * 9 * Cc:
         raise ValueError("depth_tail buffers too small")
     check(lib.vda_depth_tail_f16(_p(x), _p(w2), _p(b2), _p(w3), float(b3), _p(out), _p(zero_page(x.device)), B, h, w, H, W, Cc,
-                                 _stream()), "vda_depth_tail_f16")
+                                 _stream(x)), "vda_depth_tail_f16")
 
 
 def normalize_u8(frames, out, n, H, W):
     _req(frames, torch.uint8, "frames"), _req(out, F32, "out")
-    check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream()), "vda_normalize_u8_f32")
+    check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream(frames)), "vda_normalize_u8_f32")
 
 
 def gather_normalize_u8(video, idx, out, n, H, W):
     _req(video, torch.uint8, "video"), _req(idx, torch.int32, "idx"), _req(out, F32, "out")
     if idx.numel() < n or out.numel() < n * 3 * H * W:
         raise ValueError("gather_normalize buffers too small")
-    check(lib.vda_gather_normalize_u8_f32(_p(video), _p(idx), _p(out), n, video.shape[0], H, W, _stream()), "vda_gather_normalize_u8_f32")
+    check(lib.vda_gather_normalize_u8_f32(_p(video), _p(idx), _p(out), n, video.shape[0], H, W, _stream(video)), "vda_gather_normalize_u8_f32")
+
+
+def gather_resize_normalize_u8(video, idx, out, n, H0, W0, H, W):
+    """Window gather + bicubic resize to the network size + normalise: uint8 [N,H0,W0,3] -> fp32 [n,3,H,W]."""
+    _req(video, torch.uint8, "video"), _req(idx, torch.int32, "idx"), _req(out, F32, "out")
+    if idx.numel() < n or out.numel() < n * 3 * H * W or video.numel() < video.shape[0] * H0 * W0 * 3:
+        raise ValueError("gather_resize_normalize buffers too small")
+    check(lib.vda_gather_resize_normalize_u8_f32(_p(video), _p(idx), _p(out), n, video.shape[0], H0, W0, H, W, _stream(video)),
+          "vda_gather_resize_normalize_u8_f32")
 
 
 LSQ_BLOCKS = 256
@@ -195,7 +229,7 @@ def lsq_scale_shift(pred, target, workspace, scale_shift):
     _req(pred, F32, "pred"), _req(target, F32, "target"), _req(workspace, torch.float64, "workspace"), _req(scale_shift, F32, "scale_shift")
     if pred.numel() != target.numel() or workspace.numel() < 4 * LSQ_BLOCKS or scale_shift.numel() < 2:
         raise ValueError("lsq_scale_shift: mismatched sizes")
-    check(lib.vda_lsq_scale_shift_f32(_p(pred), _p(target), pred.numel(), _p(workspace), LSQ_BLOCKS, _p(scale_shift), _stream()),
+    check(lib.vda_lsq_scale_shift_f32(_p(pred), _p(target), pred.numel(), _p(workspace), LSQ_BLOCKS, _p(scale_shift), _stream(pred)),
           "vda_lsq_scale_shift_f32")
 
 
@@ -205,7 +239,7 @@ def stitch_window(win, scale_shift, chunk, tail, ref1, px, wts):
         _req(t, F32, nm)
     if win.numel() < 32 * px or chunk.numel() < 22 * px or tail.numel() < 8 * px or ref1.numel() < px or wts.numel() < 16:
         raise ValueError("stitch_window buffers too small")
-    check(lib.vda_stitch_window_f32(_p(win), _p(scale_shift), _p(chunk), _p(tail), _p(ref1), px, _p(wts), _stream()), "vda_stitch_window_f32")
+    check(lib.vda_stitch_window_f32(_p(win), _p(scale_shift), _p(chunk), _p(tail), _p(ref1), px, _p(wts), _stream(win)), "vda_stitch_window_f32")
 
 
 # ---------------------------------------------------------------------------
@@ -215,38 +249,38 @@ def pad_to(n, m=64):
     return (n + m - 1) // m * m
 
 
-def pack_linear(w, n_pad=None, k_pad=None):
-    """[N,K] fp32 -> fp16 [Npad,Kpad], zero padded."""
+def pack_linear(w, n_pad=None, k_pad=None, dtype=F16):
+    """[N,K] fp32 -> `dtype` [Npad,Kpad], zero padded."""
     N, K = w.shape
     n_pad = N if n_pad is None else n_pad
     k_pad = K if k_pad is None else k_pad
-    o = torch.zeros(n_pad, k_pad, dtype=F16, device=w.device)
-    o[:N, :K] = w.to(F16)
+    o = torch.zeros(n_pad, k_pad, dtype=dtype, device=w.device)
+    o[:N, :K] = w.to(dtype)
     return o
 
 
-def pack_conv3x3(w, cout_pad=None, cin_pad=None):
-    """Conv2d weight [Cout,Cin,3,3] -> fp16 [Coutpad, 9*Cinpad] with K ordered (ky,kx,ci)."""
+def pack_conv3x3(w, cout_pad=None, cin_pad=None, dtype=F16):
+    """Conv2d weight [Cout,Cin,3,3] -> `dtype` [Coutpad, 9*Cinpad] with K ordered (ky,kx,ci)."""
     Co, Ci = w.shape[:2]
     cout_pad = Co if cout_pad is None else cout_pad
     cin_pad = Ci if cin_pad is None else cin_pad
-    o = torch.zeros(cout_pad, 3, 3, cin_pad, dtype=F16, device=w.device)
-    o[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1).to(F16)
+    o = torch.zeros(cout_pad, 3, 3, cin_pad, dtype=dtype, device=w.device)
+    o[:Co, :, :, :Ci] = w.permute(0, 2, 3, 1).to(dtype)
     return o.reshape(cout_pad, 9 * cin_pad).contiguous()
 
 
-def pack_convt(w, bias, cpad):
-    """ConvTranspose2d (k == stride) weight [Cin,Cout,k,k] -> fp16 [(ky,kx,co) = k*k*cpad, cpad(ci)],
+def pack_convt(w, bias, cpad, dtype=F16):
+    """ConvTranspose2d (k == stride) weight [Cin,Cout,k,k] -> `dtype` [(ky,kx,co) = k*k*cpad, cpad(ci)],
     bias expanded to the same row order."""
     Ci, Co, k, _ = w.shape
-    o = torch.zeros(k, k, cpad, cpad, dtype=F16, device=w.device)
-    o[:, :, :Co, :Ci] = w.permute(2, 3, 1, 0).to(F16)
+    o = torch.zeros(k, k, cpad, cpad, dtype=dtype, device=w.device)
+    o[:, :, :Co, :Ci] = w.permute(2, 3, 1, 0).to(dtype)
     bb = torch.zeros(k, k, cpad, dtype=F32, device=w.device)
     bb[:, :, :Co] = bias.to(F32)
     return o.reshape(k * k * cpad, cpad).contiguous(), bb.reshape(-1).contiguous()
 
 
-def pack_geglu(w, bias):
+def pack_geglu(w, bias, dtype=F16):
     """GEGLU proj [8C, C]: rows [value(4C) | gate(4C)] -> interleaved [16 value | 16 gate] per 32 rows."""
     two_n, K = w.shape
     n = two_n // 2
@@ -255,4 +289,4 @@ def pack_geglu(w, bias):
     wi = torch.stack((wv, wg), dim=1).reshape(two_n, K)
     bv, bg = bias[:n].reshape(n // 16, 16), bias[n:].reshape(n // 16, 16)
     bi = torch.stack((bv, bg), dim=1).reshape(two_n)
-    return wi.to(F16).contiguous(), bi.to(F32).contiguous()
+    return wi.to(dtype).contiguous(), bi.to(F32).contiguous()

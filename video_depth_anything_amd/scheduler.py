@@ -57,18 +57,52 @@ def plan_windows(n_frames: int) -> List[List[int]]:
 
 
 def shard_windows(n_windows: int, world: int, rank: int) -> range:
-    """Contiguous block partition: the first (n % world) ranks take one extra window."""
-    q, r = divmod(n_windows, world)
-    lo = rank * q + min(rank, r)
-    return range(lo, lo + q + (1 if rank < r else 0))
+    """Round-robin partition: rank r computes windows r, r + world, r + 2*world, ... Round j of the job therefore holds the
+    CONSECUTIVE windows j*world .. j*world + world - 1, one per rank: the all-gather of a round delivers windows in stitch
+    order and the stitcher can run behind the rounds with a bounded ring of gathered windows."""
+    return range(rank, n_windows, world)
 
 
-def gathered_order(n_windows: int, world: int) -> Tuple[int, List[int]]:
-    """Layout of the all-gather: every rank sends `per` window slots (short ranks pad); returns (per, flat slot index
-    r * per + j of window 0, 1, 2, ... in window order)."""
-    per = (n_windows + world - 1) // world
-    order = [r * per + j for r in range(world) for j in range(len(shard_windows(n_windows, world, r)))]
-    return per, order
+def rounds(n_windows: int, world: int) -> int:
+    return (n_windows + world - 1) // world
+
+
+def drive_windows(n_windows: int, world: int, rank: int, send, recv, compute, gather):
+    """THE multi-rank schedule of infer_video_depth (device path and CPU rehearsal alike): yields every window's depth map,
+    in window order, on every rank.
+
+      send     ring of >= 2 buffers [32,H0,W0]: compute(k, send[s]) fills one with window k
+      recv     ring of >= 2 buffers [world,32,H0,W0] (None when world == 1)
+      gather   gather(recv[s], send[s]) -> handle with .wait() (or None when the call is synchronous): recv[s][r] = rank r's send[s]
+
+    Round j: this rank computes window j*world + rank (if it exists) and starts the round's all-gather; the PREVIOUS round's
+    gather is then waited for and its windows are yielded, so the exchange of round j runs under the compute of round j + 1
+    and the consumer (the stitcher) works one round behind. A slot of the rings is reused two rounds later, after the
+    consumer has taken (queued its reads of) everything yielded from it."""
+    if world == 1:
+        for k in range(n_windows):
+            yield compute(k, send[k % len(send)])
+        return
+    pending = None
+
+    def harvest(p):
+        j, s, h = p
+        if h is not None:
+            h.wait()
+        for r in range(world):
+            if j * world + r < n_windows:
+                yield recv[s][r]
+
+    for j in range(rounds(n_windows, world)):
+        s = j % len(send)
+        k = j * world + rank
+        if k < n_windows:
+            compute(k, send[s])
+        h = gather(recv[s], send[s])
+        if pending is not None:
+            yield from harvest(pending)
+        pending = (j, s, h)
+    yield from harvest(pending)
 
 
 # ------------------------------------------------------------------ stitching
@@ -129,42 +163,31 @@ def stitch_windows(window_depths: Sequence[np.ndarray], n_frames: int, metric: b
     return np.stack(aligned[:n_frames], axis=0)
 
 
-# ------------------------------------------------------------------ driver (single or multi rank)
-def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray] = None, metric: bool = False,
-                group=None, batch_fn: Callable[[List[List[int]]], List[np.ndarray]] = None) -> np.ndarray:
-    """Compute every window with `window_fn(frames_u8[32,H0,W0,3]) -> float32 [32,H0,W0]` (or, pipelined,
-    `batch_fn(list of 32-index lists) -> list of float32 [32,H0,W0]` over this rank's windows), stitch.
-
-    With torch.distributed initialised (one process per GPU; NCCL == RCCL over xGMI, gloo on CPU),
-    windows are block-partitioned over the ranks, there is no data-path collective while they are
-    computed, and ONE all-gather of the per-window depth maps precedes the (cheap, sequential)
-    stitch, which every rank then runs redundantly so all ranks return the full sequence."""
+# ------------------------------------------------------------------ host driver (CPU rehearsal of the multi-rank schedule)
+def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray], metric: bool = False, group=None) -> np.ndarray:
+    """infer_video_depth's schedule on the host: `window_fn(frames_u8[32,H0,W0,3]) -> float32 [32,H0,W0]` per window, the
+    same `drive_windows` rounds / ring / gather order the device path uses (gloo on CPU tensors instead of RCCL), then the
+    numpy stitcher. Every rank returns the full sequence. Used by the CPU tests (world size 1, 2, 3)."""
     import torch
     import torch.distributed as dist
 
     n = frames.shape[0]
+    H0, W0 = frames.shape[1:3]
     plan = plan_windows(n)
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
-    mine = shard_windows(len(plan), world, rank)
-    if batch_fn is not None:
-        local = [np.ascontiguousarray(d, dtype=np.float32) for d in batch_fn([plan[k] for k in mine])]
-    else:
-        local = [np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32) for k in mine]
-    if world == 1:
-        return stitch_windows(local, n, metric)
+    send = [torch.zeros(INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)]
+    recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)] if world > 1 else None
 
-    H0, W0 = frames.shape[1:3]
-    per, order = gathered_order(len(plan), world)               # short ranks pad to a common count
-    use_cuda = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
-    send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-    if local:
-        send[:len(local)] = torch.from_numpy(np.stack(local)).to(dev)
-    recv = torch.empty(world * per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.cpu().numpy()
-    return stitch_windows([recv[i] for i in order], n, metric)
+    def compute(k, out):
+        out.copy_(torch.from_numpy(np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32)))
+        return out
+
+    def gather(out, inp):
+        return dist.all_gather_into_tensor(out.view(world * INFER_LEN, H0, W0), inp, group=group, async_op=True)
+
+    wins = [w.numpy().copy() for w in drive_windows(len(plan), world, rank, send, recv, compute, gather)]
+    return stitch_windows(wins, n, metric)
 
 
 def normalize_frames_host(frames_u8: np.ndarray) -> np.ndarray:

@@ -4,22 +4,24 @@ Same constructor arguments, `load_state_dict(sd, strict=True)`, `forward(x)` and
 `infer_video_depth(frames, target_fps, input_size=518, device='cuda', fp32=False)` as
 /root/reference/video_depth_anything/video_depth.py:37-63,89-93,161-254, so the four callers
 (run.py:45-50, metric_depth/run.py:43-48, app.py:34-48, benchmark/infer/infer.py:36-58) can switch
-by changing one import. All arithmetic runs in libvda_hip.so; see engine.py.
-"""
-import warnings
+by changing one import. All arithmetic runs in libvda_hip.so: the model is a `vda_model` handle of the C ABI
+(handle.py -> csrc/host.hip), preprocessing / resize / stitch are per-kernel entry points.
 
+Precision follows the reference: `infer_video_depth(..., fp32=False)` is its autocast path (fp16 MFMA operands, fp32
+accumulation and residual streams), `fp32=True` its full-fp32 path (fp32 operands on fp32-input MFMA). A bare
+`model(x)` takes the precision from the ambient `torch.autocast` state exactly as the reference's nn.Module would
+(fp32 outside autocast, fp16 inside); pass `fp32=` to be explicit.
+"""
 import numpy as np
 import torch
 
 from .config import INFER_LEN, get_config
 from .scheduler import network_size
 
-_FP32_WARNED = False
-
 
 def _all_gather(out, inp):
     """out[r] = rank r's `inp`. NCCL (= RCCL): asynchronous on the collective's own stream, returns the work handle.
-    Any other backend (gloo: the 2-ranks-on-one-GPU rehearsal of tests/test_forward_gpu.py) is staged through the host."""
+    Any other backend (gloo: the ranks-share-one-GPU rehearsal of tests/test_forward_gpu.py) is staged through the host."""
     import torch.distributed as dist
     if dist.get_backend() == "nccl":
         return dist.all_gather_into_tensor(out, inp, async_op=True)
@@ -43,6 +45,10 @@ class VideoDepthAnything:
         self.engine = None
         self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self._sd = None
+        # Multi-rank runs (torch.distributed initialised): ranks that should receive the stitched video. None = every rank
+        # (each process returns the full sequence); e.g. (0,) lets the other ranks skip the stitch and its device-to-host
+        # copies - they return (None, target_fps).
+        self.result_ranks = None
 
     # ---- nn.Module-like surface used by the callers -------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -57,6 +63,11 @@ class VideoDepthAnything:
         device = torch.device(device)
         if device.type != 'cuda':
             raise RuntimeError("video_depth_anything_amd runs on an MI355X HIP device only (got device=%r)" % (device,))
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if self.engine is not None and device != self.engine.device:
+            self.engine.close()                   # the handle is bound to one device: rebuild it on the new one
+            self.engine = None
         self._device = device
         self._ensure_engine()
         return self
@@ -69,105 +80,114 @@ class VideoDepthAnything:
 
     def _ensure_engine(self):
         if self.engine is None:
-            from .engine import Engine            # imports the HIP library; fails loudly if it is missing
-            self.engine = Engine(self.cfg, self._device)
+            from .handle import ModelHandle       # imports the HIP library; fails loudly if it is missing
+            self.engine = ModelHandle(self.cfg, self._device)
             if self._sd is not None:
                 self.engine.load_state_dict(self._sd, True)
         return self.engine
 
+    def python_engine(self):
+        """The Python launch sequence over the per-kernel ABI (engine.py): the bit-exact cross-check of the handle."""
+        from .engine import Engine
+        e = Engine(self.cfg, self._ensure_engine().device)
+        e.load_state_dict(self._sd, True)
+        return e
+
     # ---- forward -----------------------------------------------------------------------------
-    def forward(self, x):
+    def forward(self, x, fp32=None):
         """x [B,T,3,H,W] (H, W multiples of 14, T <= 32) -> depth fp32 [B,T,H,W]."""
-        return self._ensure_engine().forward(x)
+        if fp32 is None:
+            fp32 = not torch.is_autocast_enabled()
+        return self._ensure_engine().forward(x, fp32=bool(fp32))
 
     __call__ = forward
 
     # ---- video inference ---------------------------------------------------------------------
     def infer_video_depth(self, frames, target_fps, input_size=518, device='cuda', fp32=False):
-        global _FP32_WARNED
         if torch.device(device).type != 'cuda':
             raise RuntimeError("video_depth_anything_amd runs on an MI355X HIP device only (got device=%r)" % (device,))
-        if fp32 and not _FP32_WARNED:
-            warnings.warn("fp32=True: this build computes with fp16 MFMA operands and fp32 accumulation/residuals; "
-                          "an fp32-operand path is not built yet")
-            _FP32_WARNED = True
-        from . import ops
         eng = self._ensure_engine()
+        with torch.cuda.device(eng.device):
+            return self._infer_video_depth(eng, frames, target_fps, input_size, bool(fp32))
+
+    def _infer_video_depth(self, eng, frames, target_fps, input_size, fp32):
+        import torch.distributed as dist
+        from . import ops
+        from .scheduler import drive_windows, plan_windows, shard_windows
+        from .stitch import stitch_stream
         frames = np.asarray(frames)
         if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
             frames = np.ascontiguousarray(frames).astype(np.uint8)
         H0, W0 = frames.shape[1:3]
         H, W = network_size(H0, W0, input_size)
-
-        import torch.distributed as dist
-        from .scheduler import gathered_order, plan_windows, shard_windows
-        from .stitch import stitch_stream
         dev = eng.device
         n = frames.shape[0]
         plan = plan_windows(n)
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
-        # The uint8 video lives in HBM and every frame crosses PCIe ONCE - but not all up front: the prefix a window needs is
-        # uploaded on a side stream while the previous window computes (window k reads frames <= 22k + 31 only).
+        mine = list(shard_windows(len(plan), world, rank))
+
+        # The uint8 frames THIS rank's windows read (frame 0, the previous window's key frame and its own 30 frames each -
+        # SURVEY.md section 8e) live in HBM in a compact buffer, and each crosses PCIe once - not all up front: what the next
+        # window needs is uploaded on a side stream while the current one computes.
         frames = np.ascontiguousarray(frames)
         host = torch.from_numpy(frames)
-        video = torch.empty((n, H0, W0, 3), dtype=torch.uint8, device=dev)
+        need = sorted({f for k in mine for f in plan[k]})
+        slot_of = {f: i for i, f in enumerate(need)}
+        video = torch.empty((max(len(need), 1), H0, W0, 3), dtype=torch.uint8, device=dev)
         compute = torch.cuda.current_stream(dev)
         upload = torch.cuda.Stream(device=dev)
-        resident = [0]                                                          # frames [0, resident) are on the device
+        resident = set()
 
-        def ensure(upto):
-            upto = min(upto, n)
-            if upto > resident[0]:
-                with torch.cuda.stream(upload):
-                    video[resident[0]:upto].copy_(host[resident[0]:upto], non_blocking=True)
-                resident[0] = upto
+        def ensure(k):
+            """Queue the upload of window k's not-yet-resident frames (runs of consecutive frames = one copy each)."""
+            if k is None:
+                return
+            todo = sorted(f for f in set(plan[k]) if f not in resident)
+            with torch.cuda.stream(upload):
+                i = 0
+                while i < len(todo):
+                    j = i
+                    while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1:
+                        j += 1
+                    s0 = slot_of[todo[i]]
+                    video[s0:s0 + (j - i + 1)].copy_(host[todo[i]:todo[j] + 1], non_blocking=True)
+                    i = j + 1
+            resident.update(todo)
 
-        xin = torch.empty(1, INFER_LEN, 3, H0, W0, dtype=torch.float32, device=dev)
+        xin = torch.empty(1, INFER_LEN, 3, H, W, dtype=torch.float32, device=dev)
 
-        def window_depth(idxs, out, prefetch_upto=0):
-            """One window on the device: gather + normalise (video_depth.py:197-201), forward, resize to the source
-            size (video_depth.py:207-208) into out [32,H0,W0]. `prefetch_upto`: frames the NEXT window will need."""
-            ensure(max(idxs) + 1)
+        def window_depth(k, out):
+            """Window k on the device: gather (+ resize to the network size) + normalise (video_depth.py:197-201,
+            util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into out [32,H0,W0]."""
+            ensure(k)
             compute.wait_stream(upload)
-            idx = torch.tensor(idxs, dtype=torch.int32, device=dev)
-            ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)
-            x = xin
-            if (H0, W0) != (H, W):
-                # Reference: cv2.resize(INTER_CUBIC) BEFORE normalisation (util/transform.py:113). cv2 is absent offline,
-                # so this leg is PARITY UNPINNED: device bicubic (a=-0.75, half-pixel centres); normalisation is affine,
-                # so resizing after it is equivalent.
-                x = torch.nn.functional.interpolate(xin[0], size=(H, W), mode='bicubic', align_corners=False)[None]
-            depth = eng.forward(x)                                               # [1,32,H,W] fp32
+            idx = torch.tensor([slot_of[f] for f in plan[k]], dtype=torch.int32, device=dev)
+            if (H0, W0) == (H, W):
+                ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)
+            else:
+                # cv2.resize(INTER_CUBIC) in the reference (util/transform.py:113); cv2 is absent offline, so this leg is
+                # PARITY UNPINNED against cv2 itself: the kernel evaluates cv2's published definition (a = -0.75, half-pixel
+                # centres, clamped taps) and is tested against that definition on the CPU.
+                ops.gather_resize_normalize_u8(video, idx, xin, INFER_LEN, H0, W0, H, W)
+            depth = eng.forward(xin, fp32=fp32)                                  # [1,32,H,W] fp32
             ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)
-            ensure(prefetch_upto)                                                # overlaps this window's compute
+            pos = mine.index(k)
+            ensure(mine[pos + 1] if pos + 1 < len(mine) else None)              # overlaps this window's compute
             return out
 
-        def upto_of(k):
-            return max(plan[k]) + 1 if k < len(plan) else 0
-
-        if world == 1:
-            wbuf = torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            windows = (window_depth(plan[k], wbuf, upto_of(k + 1)) for k in range(len(plan)))   # lazily: stitch k queues behind forward k
-        else:
-            # One process per GPU: this rank computes its block of windows with no data-path collective; each finished window
-            # is all-gathered (RCCL over xGMI; asynchronously, under the next window's compute) so that every rank ends up
-            # with all depth maps and stitches the whole sequence on its own GPU. Ranks with one window fewer send a zero slot.
-            per, _ = gathered_order(len(plan), world)
-            mine = shard_windows(len(plan), world, rank)
-            send = torch.zeros(per, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            recv = torch.empty(per, world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev)
-            pending = []
-            for j in range(per):
-                if j < len(mine):
-                    k = mine[j]
-                    window_depth(plan[k], send[j], upto_of(k + 1) if j + 1 < len(mine) else 0)
-                pending.append(_all_gather(recv[j], send[j]))
-            for h in pending:
-                if h is not None:
-                    h.wait()
-            counts = [len(shard_windows(len(plan), world, r)) for r in range(world)]
-            windows = (recv[j, r] for r in range(world) for j in range(counts[r]))     # window order = rank-major blocks
+        # One process per GPU: rank r computes windows r, r + world, ... with no data-path collective; after each round the
+        # finished windows are all-gathered (RCCL over xGMI; asynchronously, under the next round's compute) and handed to the
+        # stitcher in window order, so only a two-slot ring of gathered windows ever exists. Ranks without a window in the last
+        # round contribute an unused slot.
+        send = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)]
+        recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
+        windows = drive_windows(len(plan), world, rank, send, recv, window_depth, _all_gather)
+        if self.result_ranks is not None and rank not in self.result_ranks:
+            for _ in windows:                                                    # compute and exchange; no stitch, no D2H
+                pass
+            torch.cuda.current_stream(dev).synchronize()
+            return None, target_fps
         depths = stitch_stream(windows, n, H0, W0, dev, metric=self.METRIC)
         return depths, target_fps
 
