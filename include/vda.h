@@ -99,6 +99,13 @@ int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const floa
                           int rows, int D, int group, int skip,
                           const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream);
 
+/* Residual add + LayerNorm in one pass (dinov2_layers/block.py:105-106 followed by :56/:68 of the next sub-block):
+ *   x[r,:] += gamma[:] * y[r,:]   (x fp32 in place; y fp16 = the bias-added projection output; gamma = LayerScale, NULL = 1)
+ *   out[r',:] = LayerNorm(x[r,:]) (fp16; group/skip as above)
+ * The rounding of y to fp16 before the LayerScale multiply is the reference's own under autocast (the Linear returns fp16,
+ * layer_scale.py:28 promotes to fp32). */
+int vda_layernorm_residual_f32_f16(float* x, const void* y, const float* gamma, void* out, const float* w, const float* b,
+                                   float eps, int rows, int D, int group, int skip, vda_stream_t stream);
 /* fp32-operand path: same, fp32 out. */
 int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const float* b, float eps,
                           int rows, int D, int group, int skip,
@@ -247,6 +254,10 @@ int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, 
 /* Parity hook: copy `bytes` of a named intermediate of the last forward ("tap0".."tap3", "l1", "l2", "l3t", "l4t", "p4t",
  * "p3t", "p2", "p1"; activation dtype of that forward's precision, channels padded to multiples of 64) to device `dst`. */
 int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream);
+/* Launch-sequence switches (A/B and cross-checks). "residual_in_ln" (default 1, fp16 path only): attn.proj / mlp.fc2 store
+ * their output as fp16 and the residual add runs inside the following LayerNorm (vda_layernorm_residual_f32_f16); 0 = the add
+ * is the GEMM's fp32 in-place epilogue (VDA_EPI_SCALE_RES_F32). Changes the workspace size. */
+int vda_set_option(vda_model* h, const char* name, int value);
 /* Measurement hook (bench.py): from vda_profile_start until vda_profile_stop every `every`-th GEMM / conv launch of each
  * (shape, epilogue) inside vda_forward is bracketed by two events on the launch stream. vda_profile_stop waits for them and
  * writes a JSON object {kernel: {"launches", "flops", "timed", "timed_ms", "timed_flops"}} into json[cap]. */

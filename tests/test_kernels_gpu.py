@@ -216,6 +216,25 @@ def test_layernorm_drop_cls_and_pe(ops):
     close(out, ref.reshape(-1, D), what="layernorm + pe")
 
 
+@pytest.mark.parametrize("D,G,nb,gamma", [(1024, 13, 5, True), (384, 7, 9, True), (128, 5, 4, False)])
+def test_layernorm_residual(ops, D, G, nb, gamma):
+    """x += gamma * y in place, then LayerNorm(x) (optionally dropping the cls row of every group): both results checked."""
+    rows = nb * G
+    x, y = rnd(rows, D, seed=90, scale=2.0), rnd(rows, D, seed=91).to(F16)
+    g = (rnd(D, seed=92).abs() + 0.5) if gamma else None
+    w, b = rnd(D, seed=93) + 1.0, rnd(D, seed=94)
+    xs = x + (g if gamma else 1.0) * y.float()
+    for group, skip in ((0, 0), (G, 1)):
+        xd = dev(x.clone())
+        out = torch.full((rows - (nb if group else 0), D), float("nan"), dtype=F16, device="cuda")
+        ops.layernorm_residual(xd, dev(y), dev(g) if gamma else None, out, dev(w), dev(b), 1e-6, rows, D, group=group, skip=skip)
+        close(xd, xs, rtol=1e-6, atol=1e-6, what="residual stream")
+        ref = F.layer_norm(xs, (D,), w, b, 1e-6)
+        if group:
+            ref = ref.reshape(nb, G, D)[:, 1:].reshape(-1, D)
+        close(out, ref, what="layernorm of the updated stream")
+
+
 @pytest.mark.parametrize("Cc,hw,frames", [(64, 37, 3), (192, 50, 2), (1024, 19, 2), (384, 361, 2)])
 def test_groupnorm(ops, Cc, hw, frames):
     x = (rnd(frames, hw, Cc, seed=40, scale=2.0) + 0.7).to(F16)

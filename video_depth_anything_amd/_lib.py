@@ -43,6 +43,7 @@ SIGNATURES = {
     "vda_gemm_set_variant": (_i, [_i]),
     "vda_gemm_last_kernel": (C.c_char_p, []),
     "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "vda_layernorm_residual_f32_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_layernorm_f32_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_groupnorm_nhwc_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "vda_prepare": (_i, [_vp, _i, _i, _i, _i, _i]),
     "vda_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vda_debug_copy": (_i, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
+    "vda_set_option": (_i, [_vp, C.c_char_p, _i]),
     "vda_profile_start": (_i, [_vp, _i]),
     "vda_profile_stop": (_i, [_vp, C.c_char_p, _i]),
 }

@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int b = bh / H, head = bh - b * H;
 
     const size_t rs = (size_t)3 * H * HD;                       // row stride of qkv in halves
+    const unsigned rs32 = (unsigned)rs;                         // one frame's N * rs fits 32 bits (checked by the launcher)
     const h16* Qb = qkv + (size_t)b * N * rs + head * HD;
     const h16* Kb = Qb + (size_t)H * HD;
     const h16* Vb = Kb + (size_t)H * HD;
@@ -72,9 +73,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int j = 0; j < 2; ++j) {
             const int piece = wave + 4 * j;
             const int row = piece * 8 + lrow;
-            const size_t key = (size_t)min(kt * BKV + row, N - 1);
-            glds16(Kb + key * rs + ((lpos ^ k_swz(row)) << 3), buf + piece * 1024);
-            glds16(Vb + key * rs + ((lpos ^ v_swz(row)) << 3), buf + TILE_BYTES + piece * 1024);
+            const unsigned key = (unsigned)min(kt * BKV + row, N - 1) * rs32;     // 32-bit: one multiply, no 64-bit carry chain
+            glds16(Kb + (key + ((lpos ^ k_swz(row)) << 3)), buf + piece * 1024);
+            glds16(Vb + (key + ((lpos ^ v_swz(row)) << 3)), buf + TILE_BYTES + piece * 1024);
         }
     };
 
@@ -254,6 +255,7 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     const int nqb = (N + BQ - 1) / BQ;
     const long long total = (long long)nqb * B * heads;
     VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
+    VDA_REQUIRE((long long)N * 3 * heads * HD < (1ll << 31), "vda_attention_f16: one frame's qkv exceeds 32-bit element offsets");
     hipStream_t s = (hipStream_t)stream;
     if (g_attn_variant == 3)
         hipLaunchKernelGGL((attn_kernel<true, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);

@@ -13,6 +13,7 @@
 // seen), so a steady-state forward is graph-capturable.
 #include "vda_common.h"
 #include <string.h>
+#include <exception>
 #include <array>
 #include <map>
 #include <string>
@@ -142,6 +143,7 @@ struct vda_model {
     int ocp[4] = {0, 0, 0, 0}, Fhp = 0;
     std::array<int, 5> last_key = {0, 0, 0, 0, -1};
     Profile prof;
+    int residual_in_ln = 1;                   // vda_set_option("residual_in_ln"): see Run::forward
 };
 
 namespace {
@@ -432,8 +434,9 @@ struct Run {
     }
     void* act(const std::string& name, size_t elems) { return buf(name, elems, ab); }
     float* f32(const std::string& name, size_t elems) { return (float*)buf(name, elems, 4); }
-    const void* W(const std::string& k) const { return h->mat[prec].at(k); }
-    const float* V(const std::string& k) const { return h->vec.at(k); }
+    // packed weights by key; a dry pass may run before this precision's pack exists and never dereferences them
+    const void* W(const std::string& k) const { return dry ? nullptr : h->mat[prec].at(k); }
+    const float* V(const std::string& k) const { return dry ? nullptr : h->vec.at(k); }
 
     int gemm(vda_gemm_args a) {
         if (dry) return 0;
@@ -586,21 +589,50 @@ struct Run {
         void* hid = act("hid", (size_t)rows * 4 * D);
         void* taps[4] = {nullptr, nullptr, nullptr, nullptr};
         int ntap = 0;
+        // fp16-operand path, residual_in_ln (default): the two projections of a block (attn.proj, mlp.fc2) store their bias-added
+        // output y as fp16 and the residual add x += gamma * y rides on the LayerNorm that follows (vda_layernorm_residual_f32_f16):
+        // the GEMM epilogue writes 2 B per element instead of reading and writing the fp32 stream. Otherwise (and always on the
+        // fp32-operand path) the add is the GEMM's own epilogue (VDA_EPI_SCALE_RES_F32).
+        const bool defer = prec == VDA_PREC_F16 && h->residual_in_ln != 0;
+        void* yb = defer ? act("ybuf", (size_t)rows * D) : nullptr;
+        auto ln_res = [&](const float* gamma, void* out, const float* w, const float* b, int group, int skip) -> int {
+            if (dry) return 0;
+            return vda_layernorm_residual_f32_f16(tok, yb, gamma, out, w, b, ENC_LN_EPS, rows, D, group, skip, s);
+        };
+        bool xn_ready = false;                 // norm1 of block i already ran (fused with block i-1's fc2 residual)
         for (int i = 0; i < c.depth; ++i) {
             const std::string k = "b" + std::to_string(i) + ".";
-            VDA_TRY(layernorm(tok, xn, V(k + "norm1.weight"), V(k + "norm1.bias"), ENC_LN_EPS, rows, D));
+            if (!xn_ready) VDA_TRY(layernorm(tok, xn, V(k + "norm1.weight"), V(k + "norm1.bias"), ENC_LN_EPS, rows, D));
+            xn_ready = false;
             VDA_TRY(dense(xn, W(k + "attn.qkv.weight"), qkv, VDA_EPI_BIAS_F16, rows, 3 * D, D, V(k + "attn.qkv.bias")));
             if (!dry) VDA_TRY(prec == VDA_PREC_F32 ? vda_attention_f32((const float*)qkv, (float*)ao, BT, Nt, NH, s) : vda_attention_f16(qkv, ao, BT, Nt, NH, s));
-            VDA_TRY(dense(ao, W(k + "attn.proj.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, D, V(k + "attn.proj.bias"), tok, V(k + "ls1.gamma")));
-            VDA_TRY(layernorm(tok, xn, V(k + "norm2.weight"), V(k + "norm2.bias"), ENC_LN_EPS, rows, D));
+            if (defer) {
+                VDA_TRY(dense(ao, W(k + "attn.proj.weight"), yb, VDA_EPI_BIAS_F16, rows, D, D, V(k + "attn.proj.bias")));
+                VDA_TRY(ln_res(V(k + "ls1.gamma"), xn, V(k + "norm2.weight"), V(k + "norm2.bias"), 0, 0));
+            } else {
+                VDA_TRY(dense(ao, W(k + "attn.proj.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, D, V(k + "attn.proj.bias"), tok, V(k + "ls1.gamma")));
+                VDA_TRY(layernorm(tok, xn, V(k + "norm2.weight"), V(k + "norm2.bias"), ENC_LN_EPS, rows, D));
+            }
             VDA_TRY(dense(xn, W(k + "mlp.fc1.weight"), hid, VDA_EPI_BIAS_GELU_F16, rows, 4 * D, D, V(k + "mlp.fc1.bias")));
-            VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, 4 * D, V(k + "mlp.fc2.bias"), tok, V(k + "ls2.gamma")));
-            for (int t = 0; t < 4; ++t)
-                if (c.taps[t] == i && ntap < 4) {
-                    void* tp = act("tap" + std::to_string(ntap), (size_t)BT * P * D);
-                    VDA_TRY(layernorm(tok, tp, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, Nt, 1));     // final norm, cls dropped
-                    taps[ntap++] = tp;
+            bool is_tap = false;
+            for (int t = 0; t < 4; ++t) is_tap = is_tap || c.taps[t] == i;
+            const bool last = i + 1 == c.depth;
+            void* tp = (is_tap && ntap < 4) ? act("tap" + std::to_string(ntap), (size_t)BT * P * D) : nullptr;
+            if (defer) {
+                VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), yb, VDA_EPI_BIAS_F16, rows, D, 4 * D, V(k + "mlp.fc2.bias")));
+                if (last && tp != nullptr) {
+                    VDA_TRY(ln_res(V(k + "ls2.gamma"), tp, V("norm.w"), V("norm.b"), Nt, 1));            // residual + final norm, cls dropped
+                } else {
+                    const std::string kn = "b" + std::to_string(last ? i : i + 1) + ".";                   // residual + the next block's norm1
+                    VDA_TRY(ln_res(V(k + "ls2.gamma"), xn, V(kn + "norm1.weight"), V(kn + "norm1.bias"), 0, 0));
+                    xn_ready = true;
+                    if (tp != nullptr) VDA_TRY(layernorm(tok, tp, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, Nt, 1));
                 }
+            } else {
+                VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, 4 * D, V(k + "mlp.fc2.bias"), tok, V(k + "ls2.gamma")));
+                if (tp != nullptr) VDA_TRY(layernorm(tok, tp, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, Nt, 1));     // final norm, cls dropped
+            }
+            if (tp != nullptr) taps[ntap++] = tp;
         }
         if (ntap != 4) {
             vda_set_error("vda_forward: the configuration's taps are not four distinct block indices below depth");
@@ -748,7 +780,7 @@ extern "C" int vda_destroy(vda_model* h) {
 
 extern "C" int vda_num_weights(const vda_model* h) { return h ? (int)h->spec.size() : 0; }
 
-extern "C" int vda_load_weight(vda_model* h, const char* name, const void* ptr, const int64_t* dims, int ndim, int dtype) {
+static int vda_load_weight_impl(vda_model* h, const char* name, const void* ptr, const int64_t* dims, int ndim, int dtype) {
     VDA_REQUIRE(h && name && ptr && (dims || ndim == 0), "vda_load_weight: null argument");
     VDA_REQUIRE(dtype == VDA_DTYPE_F32, "vda_load_weight(%s): dtype %d (only VDA_DTYPE_F32 = 0 checkpoints are defined, run.py:46)", name, dtype);
     VDA_TRY(require_device(h, "vda_load_weight"));
@@ -779,7 +811,7 @@ extern "C" int vda_load_weight(vda_model* h, const char* name, const void* ptr, 
     return 0;
 }
 
-extern "C" int vda_finalize_weights(vda_model* h) {
+static int vda_finalize_weights_impl(vda_model* h) {
     VDA_REQUIRE(h, "vda_finalize_weights: null handle");
     VDA_TRY(require_device(h, "vda_finalize_weights"));
     std::string missing;
@@ -805,7 +837,7 @@ extern "C" int vda_finalize_weights(vda_model* h) {
 // Everything a forward of this shape / precision needs beyond the workspace: the fp32 weight pack (first fp32 use) and the
 // positional embedding at this grid (dinov2.py:179-210). Called by vda_forward; callable up front to keep the first
 // forward allocation-free.
-extern "C" int vda_prepare(vda_model* h, int B, int T, int H, int W, int precision) {
+static int vda_prepare_impl(vda_model* h, int B, int T, int H, int W, int precision) {
     VDA_REQUIRE(h && h->finalized, "vda_prepare: load every weight and call vda_finalize_weights first");
     VDA_TRY(require_device(h, "vda_prepare"));
     VDA_TRY(check_shape(h, B, T, H, W, precision));
@@ -828,7 +860,7 @@ extern "C" int vda_prepare(vda_model* h, int B, int T, int H, int W, int precisi
     return get_layout(h, B, T, H, W, precision, &lay);
 }
 
-extern "C" int64_t vda_workspace_bytes(vda_model* h, int B, int T, int H, int W, int precision) {
+static int64_t vda_workspace_bytes_impl(vda_model* h, int B, int T, int H, int W, int precision) {
     if (h == nullptr || !h->finalized) {
         vda_set_error("vda_workspace_bytes: load every weight and call vda_finalize_weights first");
         return -1;
@@ -848,7 +880,7 @@ extern "C" int vda_set_workspace(vda_model* h, void* ptr, int64_t bytes) {
     return 0;
 }
 
-extern "C" int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream) {
+static int vda_forward_impl(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream) {
     VDA_REQUIRE(h && in && out, "vda_forward: null argument");
     VDA_REQUIRE(h->finalized, "vda_forward: load every weight and call vda_finalize_weights first");
     VDA_TRY(vda_prepare(h, B, T, H, W, precision));
@@ -879,7 +911,7 @@ extern "C" int vda_forward(vda_model* h, const float* in, float* out, int B, int
 
 // Debug / parity hook: copy a named intermediate of the LAST forward (same workspace) into `dst`: "tap0".."tap3" (final-norm'd
 // patch tokens), "l1", "l2", "l3t", "l4t" (reassembled + temporal layers), "p4t", "p3t", "p2", "p1" (fusion pyramid).
-extern "C" int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream) {
+static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream) {
     VDA_REQUIRE(h && name && dst, "vda_debug_copy: null argument");
     auto it = h->layouts.find(h->last_key);
     VDA_REQUIRE(it != h->layouts.end() && h->ws, "vda_debug_copy: no forward has run");
@@ -888,6 +920,18 @@ extern "C" int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t
     VDA_REQUIRE(bytes > 0 && (size_t)bytes <= b->second.second, "vda_debug_copy: %s holds %lld bytes", name, (long long)b->second.second);
     VDA_HIP(hipMemcpyAsync(dst, (char*)h->ws + b->second.first, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
+}
+
+// Tuning / A-B switches of the launch sequence. "residual_in_ln" (default 1): see Run::forward.
+extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
+    VDA_REQUIRE(h && name, "vda_set_option: null argument");
+    if (strcmp(name, "residual_in_ln") == 0) {
+        h->residual_in_ln = value;
+        h->layouts.clear();                  // the workspace layout depends on it
+        return 0;
+    }
+    vda_set_error("vda_set_option: unknown option %s", name);
+    return 1;
 }
 
 // ---- bench.py's per-kernel timing of the GEMM / conv launches inside vda_forward
@@ -901,7 +945,7 @@ extern "C" int vda_profile_start(vda_model* h, int every) {
 
 // Closes the profile and writes one JSON object {kernel name: {"launches", "flops", "timed", "timed_ms", "timed_flops"}} into
 // `json` (NUL-terminated, at most `cap` bytes). Synchronises on the recorded events.
-extern "C" int vda_profile_stop(vda_model* h, char* json, int cap) {
+static int vda_profile_stop_impl(vda_model* h, char* json, int cap) {
     VDA_REQUIRE(h && json && cap > 2, "vda_profile_stop: bad arguments");
     Profile& pf = h->prof;
     struct Agg {
@@ -936,4 +980,67 @@ extern "C" int vda_profile_stop(vda_model* h, char* json, int cap) {
     VDA_REQUIRE((int)out.size() + 1 <= cap, "vda_profile_stop: the report needs %d bytes", (int)out.size() + 1);
     memcpy(json, out.c_str(), out.size() + 1);
     return 0;
+}
+
+extern "C" int vda_load_weight(vda_model* h, const char* name, const void* ptr, const int64_t* dims, int ndim, int dtype) {
+    try {
+        return vda_load_weight_impl(h, name, ptr, dims, ndim, dtype);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_load_weight: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int vda_finalize_weights(vda_model* h) {
+    try {
+        return vda_finalize_weights_impl(h);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_finalize_weights: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int vda_prepare(vda_model* h, int B, int T, int H, int W, int precision) {
+    try {
+        return vda_prepare_impl(h, B, T, H, W, precision);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_prepare: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream) {
+    try {
+        return vda_forward_impl(h, in, out, B, T, H, W, precision, stream);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_forward: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream) {
+    try {
+        return vda_debug_copy_impl(h, name, dst, bytes, stream);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_debug_copy: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int vda_profile_stop(vda_model* h, char* json, int cap) {
+    try {
+        return vda_profile_stop_impl(h, json, cap);
+    } catch (const std::exception& e) {        // no exception crosses the C ABI
+        vda_set_error("vda_profile_stop: %s", e.what());
+        return 3;
+    }
+}
+
+extern "C" int64_t vda_workspace_bytes(vda_model* h, int B, int T, int H, int W, int precision) {
+    try {
+        return vda_workspace_bytes_impl(h, B, T, H, W, precision);
+    } catch (const std::exception& e) {
+        vda_set_error("vda_workspace_bytes: %s", e.what());
+        return -1;
+    }
 }

@@ -38,18 +38,22 @@ __device__ __forceinline__ float segment_sum(float v, int lane) {
     return v;
 }
 
-template <int LPR, int NCH, typename OT>
-__global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict__ in, OT* __restrict__ out,
+// RES: the row is first updated in place, in[r,:] += gamma * y[r,:] (y fp16: the bias-added output of the preceding projection,
+// gamma = LayerScale or NULL = 1) - the encoder's residual add (block.py:105-106) rides on the LayerNorm that follows it, so the
+// projection GEMM stores 2 bytes per element instead of reading and writing the fp32 stream in its (fabric-bound) epilogue.
+template <int LPR, int NCH, typename OT, bool RES>
+__global__ void __launch_bounds__(256) layernorm_kernel(float* __restrict__ in, OT* __restrict__ out,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, int rows, int D, int group, int skip,
-                                                        const float* __restrict__ pe, int pe_rows_per_step, int pe_steps) {
+                                                        const float* __restrict__ pe, int pe_rows_per_step, int pe_steps,
+                                                        const h16* __restrict__ y, const float* __restrict__ gamma) {
     constexpr int RPW = 64 / LPR;                                  // rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane % LPR, rsel = lane / LPR;
     const int row = (blockIdx.x * 4 + wave) * RPW + rsel;
     const bool row_ok = row < rows;
     const int nchunk = D >> 3;                                     // 8-element chunks per row
-    const float* src = in + (size_t)(row_ok ? row : 0) * D;
+    float* src = in + (size_t)(row_ok ? row : 0) * D;
     f32x4 v[NCH][2];
     float sum = 0.f;
 #pragma unroll
@@ -60,6 +64,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
         if (ok) {
             v[c][0] = *reinterpret_cast<const f32x4*>(src + ch * 8);
             v[c][1] = *reinterpret_cast<const f32x4*>(src + ch * 8 + 4);
+            if constexpr (RES) {
+                const h16x8 yy = *reinterpret_cast<const h16x8*>(y + (size_t)row * D + ch * 8);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 g = {1.f, 1.f, 1.f, 1.f};
+                    if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + ch * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[c][h][e] = fmaf(g[e], (float)yy[h * 4 + e], v[c][h][e]);
+                    *reinterpret_cast<f32x4*>(src + ch * 8 + h * 4) = v[c][h];
+                }
+            }
         }
         sum += ((v[c][0][0] + v[c][0][1]) + (v[c][0][2] + v[c][0][3])) + ((v[c][1][0] + v[c][1][1]) + (v[c][1][2] + v[c][1][3]));
     }
@@ -208,9 +223,11 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const T* __restric
 
 }  // namespace
 
-template <typename OT>
-static int layernorm_launch(const float* in, OT* out, const float* w, const float* b, float eps, int rows, int D, int group, int skip,
-                            const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream) {
+template <typename OT, bool RES = false>
+static int layernorm_launch(float* in, OT* out, const float* w, const float* b, float eps, int rows, int D, int group, int skip,
+                            const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream, const h16* y = nullptr,
+                            const float* gamma = nullptr) {
+    VDA_REQUIRE(!RES || (y != nullptr && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0), "vda_layernorm_residual: y must be a 16-byte aligned pointer");
     VDA_REQUIRE(in && out && w && b, "vda_layernorm: null pointer");
     VDA_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048, "vda_layernorm: D=%d must be a multiple of 8 and <= 2048", D);
     VDA_REQUIRE(group == 0 || (group > 0 && skip >= 0 && skip < group && rows % group == 0), "vda_layernorm: bad group/skip");
@@ -221,8 +238,8 @@ static int layernorm_launch(const float* in, OT* out, const float* w, const floa
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = D / 8;
 #define VDA_LN_LAUNCH(LPR, NCH)                                                                                                     \
-    hipLaunchKernelGGL((layernorm_kernel<LPR, NCH, OT>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, in, \
-                       out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps)
+    hipLaunchKernelGGL((layernorm_kernel<LPR, NCH, OT, RES>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, in, \
+                       out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, y, gamma)
     if (nchunk <= 8) VDA_LN_LAUNCH(8, 1);
     else if (nchunk <= 16) VDA_LN_LAUNCH(16, 1);
     else if (nchunk <= 32) VDA_LN_LAUNCH(32, 1);
@@ -237,13 +254,18 @@ static int layernorm_launch(const float* in, OT* out, const float* w, const floa
 extern "C" int vda_layernorm_f32_f16(const float* in, void* out, const float* w, const float* b, float eps, int rows, int D,
                                      int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
                                      vda_stream_t stream) {
-    return layernorm_launch<h16>(in, (h16*)out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+    return layernorm_launch<h16>(const_cast<float*>(in), (h16*)out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+}
+
+extern "C" int vda_layernorm_residual_f32_f16(float* x, const void* y, const float* gamma, void* out, const float* w, const float* b,
+                                              float eps, int rows, int D, int group, int skip, vda_stream_t stream) {
+    return layernorm_launch<h16, true>(x, (h16*)out, w, b, eps, rows, D, group, skip, nullptr, 0, 0, stream, (const h16*)y, gamma);
 }
 
 extern "C" int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const float* b, float eps, int rows, int D,
                                      int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
                                      vda_stream_t stream) {
-    return layernorm_launch<float>(in, out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+    return layernorm_launch<float>(const_cast<float*>(in), out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
 }
 
 template <typename T>

@@ -57,6 +57,7 @@ class Engine:
         self._buf: Dict[tuple, torch.Tensor] = {}
         self._pos_cache: Dict[tuple, torch.Tensor] = {}
         self.loaded = False
+        self.residual_in_ln = True                  # fp16 path: the residual add rides on the following LayerNorm (see _forward)
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, strict=True):
@@ -287,20 +288,45 @@ class Engine:
         ao = self.buf("ao", (rows, D), self.act)
         hid = self.buf("hid", (rows, 4 * D), self.act)
         taps = []
+        # fp16 path, residual_in_ln: attn.proj / mlp.fc2 store their bias-added output y as fp16 and x += gamma * y rides on the
+        # LayerNorm that follows (vda_layernorm_residual_f32_f16): the projection's epilogue writes 2 B per element instead of
+        # reading and writing the fp32 stream. Otherwise (and always in fp32 mode) the add is the GEMM's own fp32 epilogue.
+        defer = (not fp32) and self.residual_in_ln
+        yb = self.buf("ybuf", (rows, D), F16) if defer else None
+        xn_ready = False
         for i in range(cfg.depth):
             k = f"b{i}."
-            ops.layernorm(tok, xn, w[k + "norm1.weight"], w[k + "norm1.bias"], ENC_LN_EPS, rows, D)
+            if not xn_ready:
+                ops.layernorm(tok, xn, w[k + "norm1.weight"], w[k + "norm1.bias"], ENC_LN_EPS, rows, D)
+            xn_ready = False
             ops.gemm(xn, w[k + "attn.qkv.weight"], qkv, _lib.EPI_BIAS_F16, M=rows, N=3 * D, K=D, bias=w[k + "attn.qkv.bias"])
             ops.attention(qkv, ao, BT, Nt, NH)
-            ops.gemm(ao, w[k + "attn.proj.weight"], tok, _lib.EPI_SCALE_RES_F32, M=rows, N=D, K=D, bias=w[k + "attn.proj.bias"],
-                     gamma=w[k + "ls1.gamma"], res=tok)
-            ops.layernorm(tok, xn, w[k + "norm2.weight"], w[k + "norm2.bias"], ENC_LN_EPS, rows, D)
+            if defer:
+                ops.gemm(ao, w[k + "attn.proj.weight"], yb, _lib.EPI_BIAS_F16, M=rows, N=D, K=D, bias=w[k + "attn.proj.bias"])
+                ops.layernorm_residual(tok, yb, w[k + "ls1.gamma"], xn, w[k + "norm2.weight"], w[k + "norm2.bias"], ENC_LN_EPS, rows, D)
+            else:
+                ops.gemm(ao, w[k + "attn.proj.weight"], tok, _lib.EPI_SCALE_RES_F32, M=rows, N=D, K=D, bias=w[k + "attn.proj.bias"],
+                         gamma=w[k + "ls1.gamma"], res=tok)
+                ops.layernorm(tok, xn, w[k + "norm2.weight"], w[k + "norm2.bias"], ENC_LN_EPS, rows, D)
             ops.gemm(xn, w[k + "mlp.fc1.weight"], hid, _lib.EPI_BIAS_GELU_F16, M=rows, N=4 * D, K=D, bias=w[k + "mlp.fc1.bias"])
-            ops.gemm(hid, w[k + "mlp.fc2.weight"], tok, _lib.EPI_SCALE_RES_F32, M=rows, N=D, K=4 * D, bias=w[k + "mlp.fc2.bias"],
-                     gamma=w[k + "ls2.gamma"], res=tok)
-            if i in cfg.taps:
-                tp = self.buf(f"tap{len(taps)}", (BT * P, D), self.act)
-                ops.layernorm(tok, tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
+            is_tap, last = i in cfg.taps, i + 1 == cfg.depth
+            tp = self.buf(f"tap{len(taps)}", (BT * P, D), self.act) if is_tap else None
+            if defer:
+                ops.gemm(hid, w[k + "mlp.fc2.weight"], yb, _lib.EPI_BIAS_F16, M=rows, N=D, K=4 * D, bias=w[k + "mlp.fc2.bias"])
+                if last and tp is not None:
+                    ops.layernorm_residual(tok, yb, w[k + "ls2.gamma"], tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
+                else:
+                    kn = f"b{i if last else i + 1}."
+                    ops.layernorm_residual(tok, yb, w[k + "ls2.gamma"], xn, w[kn + "norm1.weight"], w[kn + "norm1.bias"], ENC_LN_EPS, rows, D)
+                    xn_ready = True
+                    if tp is not None:
+                        ops.layernorm(tok, tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
+            else:
+                ops.gemm(hid, w[k + "mlp.fc2.weight"], tok, _lib.EPI_SCALE_RES_F32, M=rows, N=D, K=4 * D, bias=w[k + "mlp.fc2.bias"],
+                         gamma=w[k + "ls2.gamma"], res=tok)
+                if tp is not None:
+                    ops.layernorm(tok, tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
+            if tp is not None:
                 taps.append(tp)
         if taps_out is not None:
             taps_out.extend(taps)

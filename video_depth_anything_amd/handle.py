@@ -126,6 +126,9 @@ class ModelHandle:
             _check(lib.vda_debug_copy(self._h, buf.encode(), C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), stream), "vda_debug_copy")
         return t, h, w, Cp
 
+    def set_option(self, name, value):
+        _check(lib.vda_set_option(self._h, name.encode(), int(value)), "vda_set_option")
+
     def profile_start(self, every=4):
         _check(lib.vda_profile_start(self._h, every), "vda_profile_start")
 

@@ -131,6 +131,15 @@ def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_
     check(fn(_p(x), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _p(pe), pe_rows_per_step, pe_steps, _stream(x)), "vda_layernorm")
 
 
+def layernorm_residual(x, y, gamma, out, w, b, eps, rows, D, group=0, skip=0):
+    """x += gamma * y (x fp32 in place, y fp16), out = LayerNorm(x) fp16."""
+    _req(x, F32, "x"), _req(y, F16, "y"), _req(gamma, F32, "gamma"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b")
+    if x.numel() < rows * D or y.numel() < rows * D:
+        raise ValueError("layernorm_residual buffers too small")
+    check(lib.vda_layernorm_residual_f32_f16(_p(x), _p(y), _p(gamma), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _stream(x)),
+          "vda_layernorm_residual_f32_f16")
+
+
 def groupnorm(x, out, w, b, eps, frames, hw, Cc, groups, partial, chunks):
     _act(x, "x"), _req(out, x.dtype, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(partial, F32, "partial")
     if partial.numel() < frames * chunks * groups * 2:
