@@ -219,21 +219,21 @@ def test_handle_and_python_orchestration_are_bit_identical(golden_dir):
 
 
 def test_residual_in_layernorm_matches_the_epilogue_residual():
-    """The two placements of the encoder's residual add (vda_set_option "residual_in_ln": fused into the next LayerNorm with the
-    projection output stored as fp16 - the default - or the GEMM's fp32 in-place epilogue) differ only by that fp16 rounding."""
-    m, cfg, sd = model_for("vits", 14)
-    x = torch.randn(1, 3, 3, 70, 84, generator=torch.Generator().manual_seed(75)).cuda()
-    a = m.forward(x, fp32=False).clone()
-    m.engine.set_option("residual_in_ln", 0)
+    """The two placements of the encoder's residual add (vda_set_option "residual_in_ln": the GEMM's fp32 in-place epilogue - the
+    default - or fused into the next LayerNorm with the projection output stored as fp16) differ only by that fp16 rounding."""
+    m, cfg, sd = model_for("vits", 0)
+    x = torch.randn(1, 3, 3, 56, 70, generator=torch.Generator().manual_seed(102)).cuda()      # the vits_forward fixture's input
     b = m.forward(x, fp32=False).clone()
     m.engine.set_option("residual_in_ln", 1)
-    assert torch.equal(a, m.forward(x, fp32=False))
+    a = m.forward(x, fp32=False).clone()
+    m.engine.set_option("residual_in_ln", 0)
+    assert torch.equal(b, m.forward(x, fp32=False))
     e = rel_l1(a.cpu().numpy(), b.cpu().numpy())
     record("vits.residual_in_ln_vs_epilogue", e)
-    assert 0 < e < 1e-3
+    assert 0 < e < 1.4e-3           # measured 6.5e-4; each form is 6.4e-4 / 6.7e-4 from the fp32 oracle on this input (tools/res_ab.py)
     py = m.python_engine()
-    py.residual_in_ln = False
-    assert torch.equal(b, py.forward(x, fp32=False)), "both orchestrations, epilogue-residual form"
+    py.residual_in_ln = True
+    assert torch.equal(a, py.forward(x, fp32=False)), "both orchestrations, residual-in-LayerNorm form"
 
 
 def test_forward_precision_follows_autocast():

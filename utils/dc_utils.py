@@ -91,7 +91,8 @@ def read_video_frames(video_path, process_length, target_fps=-1, max_res=-1):
 
 def _inferno(u8):
     """uint8 [..] -> uint8 [..,3]: degree-6 polynomial fit of matplotlib's 'inferno' (the reference indexes the 256-entry table,
-    dc_utils.py:75-83; matplotlib is not installed here)."""
+    dc_utils.py:75-83; matplotlib is not installed here). VISUALISATION ONLY and unpinned: no fixture of the reference holds a
+    colour-mapped frame; the depth values themselves (npz / exr / the returned array) never pass through this."""
     t = u8.astype(np.float32) / 255.0
     c = np.array([[0.0002189403691192265, 0.001651004631001012, -0.01948089843709184],
                   [0.1065134194856116, 0.5639564367884091, 3.932712388889277],
@@ -118,12 +119,16 @@ def save_video(frames, output_video_path, fps=10, is_depths=False, grayscale=Fal
         vis = frames
     try:
         import imageio
+    except ImportError:
+        imageio = None                                 # no H.264 encoder in this image: animated GIF instead (stated in the docstring)
+    if imageio is not None:
+        # an encoder that IS installed and fails (bad path, codec error) raises: the failure must not turn into a silent GIF
         writer = imageio.get_writer(output_video_path, fps=fps, macro_block_size=1, codec='libx264', ffmpeg_params=['-crf', '18'])
         for f in vis:
             writer.append_data(f)
         writer.close()
         return output_video_path
-    except Exception:
+    else:
         from PIL import Image
         path = os.path.splitext(output_video_path)[0] + ".gif"
         ims = [Image.fromarray(f) for f in vis]

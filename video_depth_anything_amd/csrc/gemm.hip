@@ -280,7 +280,8 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
     if (g_gemm_variant == 2 || g_gemm_variant == 4) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
-    if (g_gemm_variant < 0 && a.N >= 192 && a.M >= 2048) {
+    static const int big_min_n = getenv("VDA_GEMM_BIG_MIN_N") ? atoi(getenv("VDA_GEMM_BIG_MIN_N")) : 192;      // A/B hook
+    if (g_gemm_variant < 0 && a.N >= big_min_n && a.M >= 2048) {
         // large-tile kernel; BN picked for the smaller padded width
         const int pad256 = (a.N + 255) / 256 * 256, pad128 = (a.N + 127) / 128 * 128;
         big = pad128 < pad256 ? 128 : 256;

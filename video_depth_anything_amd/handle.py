@@ -7,6 +7,7 @@ The reference seam it stands for: `VideoDepthAnything(**cfg)` + `load_state_dict
 """
 import ctypes as C
 import json
+import os
 
 import torch
 
@@ -40,6 +41,8 @@ class ModelHandle:
             _check(lib.vda_create(C.byref(c), C.byref(h)), "vda_create")
         self._h = h
         self._ws = None
+        if os.environ.get("VDA_RESIDUAL_IN_LN") is not None:          # A/B switch for tools / bench runs
+            _check(lib.vda_set_option(h, b"residual_in_ln", int(os.environ["VDA_RESIDUAL_IN_LN"])), "vda_set_option")
         self.loaded = False
         assert lib.vda_num_weights(self._h) == len(state_dict_spec(cfg))
 
