@@ -40,7 +40,7 @@ class ModelHandle:
         with torch.cuda.device(self.device):
             _check(lib.vda_create(C.byref(c), C.byref(h)), "vda_create")
         self._h = h
-        self._ws = None
+        self._ws = {}                            # workspace blocks by slot (a caller keeping two forwards in flight uses two)
         if os.environ.get("VDA_RESIDUAL_IN_LN") is not None:          # A/B switch for tools / bench runs
             _check(lib.vda_set_option(h, b"residual_in_ln", int(os.environ["VDA_RESIDUAL_IN_LN"])), "vda_set_option")
         self.loaded = False
@@ -83,8 +83,9 @@ class ModelHandle:
         return n
 
     @torch.no_grad()
-    def forward(self, x, fp32: bool = False):
-        """x: fp32 [B,T,3,H,W] -> depth fp32 [B,T,H,W] on the handle's device."""
+    def forward(self, x, fp32: bool = False, slot: int = 0):
+        """x: fp32 [B,T,3,H,W] -> depth fp32 [B,T,H,W] on the handle's device, enqueued on the current stream. `slot` picks the
+        workspace block: forwards that may be in flight at the same time (on different streams) must use different slots."""
         if not self.loaded:
             raise RuntimeError("load_state_dict() first")
         if x.dim() != 5 or x.shape[2] != 3:
@@ -98,10 +99,11 @@ class ModelHandle:
         with torch.cuda.device(self.device):
             x = x.to(self.device, F32).contiguous()
             need = self.workspace_bytes(B, T, H, W, fp32)
-            if self._ws is None or self._ws.numel() < need:
-                self._ws = None                          # release before growing
-                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                _check(lib.vda_set_workspace(self._h, C.c_void_p(self._ws.data_ptr()), self._ws.numel()), "vda_set_workspace")
+            ws = self._ws.get(slot)
+            if ws is None or ws.numel() < need:
+                self._ws[slot] = ws = None               # release before growing
+                self._ws[slot] = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            _check(lib.vda_set_workspace(self._h, C.c_void_p(ws.data_ptr()), ws.numel()), "vda_set_workspace")
             out = torch.empty(B, T, H, W, dtype=F32, device=self.device)
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             _check(lib.vda_forward(self._h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), B, T, H, W, prec, stream), "vda_forward")

@@ -67,21 +67,31 @@ def rounds(n_windows: int, world: int) -> int:
     return (n_windows + world - 1) // world
 
 
-def drive_windows(n_windows: int, world: int, rank: int, send, recv, compute, gather):
+def drive_windows(n_windows: int, world: int, rank: int, send, recv, compute, gather, ready=None, release=None):
     """THE multi-rank schedule of infer_video_depth (device path and CPU rehearsal alike): yields every window's depth map,
     in window order, on every rank.
 
-      send     ring of >= 2 buffers [32,H0,W0]: compute(k, send[s]) fills one with window k
+      send     ring of >= 2 buffers [32,H0,W0]: compute(k, s) fills send[s] with window k
       recv     ring of >= 2 buffers [world,32,H0,W0] (None when world == 1)
-      gather   gather(recv[s], send[s]) -> handle with .wait() (or None when the call is synchronous): recv[s][r] = rank r's send[s]
+      gather   gather(s) -> handle with .wait() (or None when the call is synchronous): recv[s][r] = rank r's send[s]
+      ready    ready(s): called before anything of slot s is yielded (device path: the consumer's stream waits for the slot's
+               compute stream - slots are computed on their own HIP streams so that two windows are in flight)
+      release  release(s): called once the consumer has taken (queued its reads of) everything yielded from slot s, i.e. before
+               the slot is overwritten two rounds later (device path: records the event the slot's next compute waits for)
 
-    Round j: this rank computes window j*world + rank (if it exists) and starts the round's all-gather; the PREVIOUS round's
-    gather is then waited for and its windows are yielded, so the exchange of round j runs under the compute of round j + 1
-    and the consumer (the stitcher) works one round behind. A slot of the rings is reused two rounds later, after the
-    consumer has taken (queued its reads of) everything yielded from it."""
+    Round j: this rank computes window j*world + rank (if it exists) into slot j % 2 and starts the round's all-gather; the
+    PREVIOUS round's gather is then waited for and its windows are yielded, so the exchange of round j runs under the compute
+    of round j + 1 and the consumer (the stitcher) works one round behind."""
+    nslot = len(send)
     if world == 1:
         for k in range(n_windows):
-            yield compute(k, send[k % len(send)])
+            s = k % nslot
+            compute(k, s)
+            if ready is not None:
+                ready(s)
+            yield send[s]
+            if release is not None:
+                release(s)
         return
     pending = None
 
@@ -89,16 +99,20 @@ def drive_windows(n_windows: int, world: int, rank: int, send, recv, compute, ga
         j, s, h = p
         if h is not None:
             h.wait()
+        if ready is not None:
+            ready(s)
         for r in range(world):
             if j * world + r < n_windows:
                 yield recv[s][r]
+        if release is not None:
+            release(s)
 
     for j in range(rounds(n_windows, world)):
-        s = j % len(send)
+        s = j % nslot
         k = j * world + rank
         if k < n_windows:
-            compute(k, send[s])
-        h = gather(recv[s], send[s])
+            compute(k, s)
+        h = gather(s)
         if pending is not None:
             yield from harvest(pending)
         pending = (j, s, h)
@@ -179,12 +193,11 @@ def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray
     send = [torch.zeros(INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)]
     recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)] if world > 1 else None
 
-    def compute(k, out):
-        out.copy_(torch.from_numpy(np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32)))
-        return out
+    def compute(k, s):
+        send[s].copy_(torch.from_numpy(np.ascontiguousarray(window_fn(frames[plan[k]]), dtype=np.float32)))
 
-    def gather(out, inp):
-        return dist.all_gather_into_tensor(out.view(world * INFER_LEN, H0, W0), inp, group=group, async_op=True)
+    def gather(s):
+        return dist.all_gather_into_tensor(recv[s].view(world * INFER_LEN, H0, W0), send[s], group=group, async_op=True)
 
     wins = [w.numpy().copy() for w in drive_windows(len(plan), world, rank, send, recv, compute, gather)]
     return stitch_windows(wins, n, metric)

@@ -155,40 +155,68 @@ class VideoDepthAnything:
                     i = j + 1
             resident.update(todo)
 
-        xin = torch.empty(1, INFER_LEN, 3, H, W, dtype=torch.float32, device=dev)
+        # Windows are independent, so TWO are kept in flight on this GPU, each on its own HIP stream with its own input buffer,
+        # workspace slot and output slot: the tail rounds and launch gaps of one window's kernels are filled by the other's
+        # (measured: +6 % ViT-L, +17 % ViT-S frames/s over one window at a time, tools/two_stream.py).
+        NSLOT = 2
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(NSLOT)]
+        computed = [torch.cuda.Event() for _ in range(NSLOT)]      # slot's window is in send[s] (recorded on its lane)
+        freed = [torch.cuda.Event() for _ in range(NSLOT)]         # the consumer is done with the slot (recorded on `compute`)
+        xin = [torch.empty(1, INFER_LEN, 3, H, W, dtype=torch.float32, device=dev) for _ in range(NSLOT)]
+        send = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(NSLOT)]
+        recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(NSLOT)] if world > 1 else None
+        used = [False] * NSLOT
 
-        def window_depth(k, out):
-            """Window k on the device: gather (+ resize to the network size) + normalise (video_depth.py:197-201,
-            util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into out [32,H0,W0]."""
+        def window_depth(k, s):
+            """Window k on lane s: gather (+ resize to the network size) + normalise (video_depth.py:197-201,
+            util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into send[s] [32,H0,W0]."""
             ensure(k)
-            compute.wait_stream(upload)
-            idx = torch.tensor([slot_of[f] for f in plan[k]], dtype=torch.int32, device=dev)
-            if (H0, W0) == (H, W):
-                ops.gather_normalize_u8(video, idx, xin, INFER_LEN, H0, W0)
-            else:
-                # cv2.resize(INTER_CUBIC) in the reference (util/transform.py:113); cv2 is absent offline, so this leg is
-                # PARITY UNPINNED against cv2 itself: the kernel evaluates cv2's published definition (a = -0.75, half-pixel
-                # centres, clamped taps) and is tested against that definition on the CPU.
-                ops.gather_resize_normalize_u8(video, idx, xin, INFER_LEN, H0, W0, H, W)
-            depth = eng.forward(xin, fp32=fp32)                                  # [1,32,H,W] fp32
-            ops.bilinear_plane(depth.view(INFER_LEN, H, W), out, INFER_LEN, H, W, H0, W0)
+            lane = lanes[s]
+            lane.wait_stream(upload)
+            if used[s]:
+                lane.wait_event(freed[s])                                        # the slot's previous window has been consumed
+            used[s] = True
+            with torch.cuda.stream(lane):
+                idx = torch.tensor([slot_of[f] for f in plan[k]], dtype=torch.int32, device=dev)
+                if (H0, W0) == (H, W):
+                    ops.gather_normalize_u8(video, idx, xin[s], INFER_LEN, H0, W0)
+                else:
+                    # cv2.resize(INTER_CUBIC) in the reference (util/transform.py:113); cv2 is absent offline, so this leg is
+                    # PARITY UNPINNED against cv2 itself: the kernel evaluates cv2's published definition (a = -0.75, half-pixel
+                    # centres, clamped taps) and is tested against that definition on the CPU.
+                    ops.gather_resize_normalize_u8(video, idx, xin[s], INFER_LEN, H0, W0, H, W)
+                depth = eng.forward(xin[s], fp32=fp32, slot=s)                   # [1,32,H,W] fp32
+                ops.bilinear_plane(depth.view(INFER_LEN, H, W), send[s], INFER_LEN, H, W, H0, W0)
+                computed[s].record(lane)
             pos = mine.index(k)
             ensure(mine[pos + 1] if pos + 1 < len(mine) else None)              # overlaps this window's compute
-            return out
+
+        def exchange(s):
+            """The one exchange of the path (RCCL all-gather over xGMI), issued on the slot's lane behind its window."""
+            with torch.cuda.stream(lanes[s]):
+                h = _all_gather(recv[s], send[s])
+                computed[s].record(lanes[s])
+            return h
+
+        def ready(s):
+            compute.wait_event(computed[s])
+
+        def release(s):
+            freed[s].record(compute)
 
         # One process per GPU: rank r computes windows r, r + world, ... with no data-path collective; after each round the
-        # finished windows are all-gathered (RCCL over xGMI; asynchronously, under the next round's compute) and handed to the
-        # stitcher in window order, so only a two-slot ring of gathered windows ever exists. Ranks without a window in the last
-        # round contribute an unused slot.
-        send = [torch.empty(INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)]
-        recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(2)] if world > 1 else None
-        windows = drive_windows(len(plan), world, rank, send, recv, window_depth, _all_gather)
+        # finished windows are all-gathered (asynchronously, under the next round's compute) and handed to the stitcher in window
+        # order, so only a two-slot ring of gathered windows ever exists. Ranks without a window in the last round contribute an
+        # unused slot.
+        windows = drive_windows(len(plan), world, rank, send, recv, window_depth, exchange, ready, release)
         if self.result_ranks is not None and rank not in self.result_ranks:
             for _ in windows:                                                    # compute and exchange; no stitch, no D2H
                 pass
-            torch.cuda.current_stream(dev).synchronize()
+            torch.cuda.synchronize(dev)
             return None, target_fps
         depths = stitch_stream(windows, n, H0, W0, dev, metric=self.METRIC)
+        for lane in lanes:
+            compute.wait_stream(lane)
         return depths, target_fps
 
 
