@@ -24,10 +24,11 @@ pytestmark = pytest.mark.gpu
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL32 = 1e-3
-# fp16-operand path: 2x the round-1 measurements (gpurun_out/parity.json at 36eef41)
+# fp16-operand path: 2x the measured value (round 1's gpurun_out/parity.json at 36eef41; the checks that are new in round 2 -
+# vitl.t32 6.3e-4, vitl.metric_video 4.4e-4, resize_video 2.2e-3 - from their first run)
 TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.nonsquare.depth": 1.4e-3, "vits.518.depth_sub": 3.0e-3,
          "vits.518.row_sums": 2.5e-3, "video.relative": 3.6e-3, "video.metric": 4.3e-3, "vitl.2x518": 2.4e-3, "vits.4x518": 7e-4,
-         "vitl.t32": 2.4e-3, "vitl.metric_video": 4.3e-3, "resize_video": 3.6e-3}
+         "vitl.t32": 1.3e-3, "vitl.metric_video": 9e-4, "resize_video": 4.4e-3}
 _measured = {}
 
 
