@@ -53,3 +53,13 @@ def test_refusal_needs_no_gpu(libpath):
     a = _lib.GemmArgs()
     assert _lib.lib.vda_gemm_f16(ctypes.byref(a), None) != 0
     assert b"null" in _lib.lib.vda_last_error()
+
+
+def test_cpp_host_demo_builds_and_links(libpath):
+    """examples/host_demo.cpp (a C++ host of the handle API) compiles against include/vda.h and links against the library;
+    argument checking happens before any HIP call."""
+    import subprocess
+    from video_depth_anything_amd import build
+    exe = build.build_host_demo()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage" in r.stderr

@@ -7,9 +7,13 @@ from video_depth_anything_amd import _lib, ops
 variants = [int(v) for v in sys.argv[1].split(",")]
 epi = int(sys.argv[2]) if len(sys.argv) > 2 else _lib.EPI_BIAS_F16
 shapes = [(43840, 4096, 1024), (43840, 1024, 4096), (43840, 3072, 1024), (43840, 1024, 1024)]
+if os.environ.get("AB_SHAPES") == "vits":
+    shapes = [(43840, 1536, 384), (43840, 384, 1536), (43840, 1152, 384), (43840, 384, 384)]
 conv = len(sys.argv) > 3 and sys.argv[3] == "conv"
 if conv:      # head convs: 3x3, 256 -> 256 channels on 32 frames of 148^2 / 74^2 / 37^2
     shapes = [(32 * 148 * 148, 256, 2304), (32 * 74 * 74, 256, 2304), (32 * 37 * 37, 256, 2304), (32 * 296 * 296, 128, 2304)]
+    if os.environ.get("AB_SHAPES") == "vits":
+        shapes = [(32 * 148 * 148, 64, 576), (32 * 74 * 74, 64, 576), (32 * 296 * 296, 64, 576), (32 * 148 * 148, 64, 1152)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for (M, N, K) in shapes:
     A = torch.randn(M, K if not conv else K // 9, device="cuda", generator=g).half()

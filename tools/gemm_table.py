@@ -13,7 +13,8 @@ sd = {k: (torch.randn(s, generator=g) * 0.02 if len(s) > 1 else torch.ones(s)) f
 m = VideoDepthAnything(encoder=enc, features=cfg.features, out_channels=list(cfg.out_channels))
 m.load_state_dict(sd); m = m.to("cuda")
 x = torch.randn(1, 32, 3, 518, 518, generator=g).cuda()
-m.forward(x, fp32=False); torch.cuda.synchronize()
+PE = m.python_engine()          # the Python launch sequence goes through ops.gemm (the handle's C++ one does not)
+PE.forward(x); torch.cuda.synchronize()
 rec = []
 orig = ops.gemm
 def wrapped(A, W, out, epi, **kw):
@@ -21,7 +22,7 @@ def wrapped(A, W, out, epi, **kw):
     e0.record(); orig(A, W, out, epi, **kw); e1.record()
     rec.append(((kw["M"], kw["N"], kw["K"], epi, "conv" if kw.get("conv") else "dense", _lib.lib.vda_gemm_last_kernel().decode()), e0, e1))
 ops.gemm = wrapped
-for _ in range(3): m.forward(x, fp32=False)
+for _ in range(3): PE.forward(x)
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
 for key, e0, e1 in rec:

@@ -66,5 +66,23 @@ def build(verbose=False):
     return LIB
 
 
+def build_host_demo(verbose=False):
+    """examples/host_demo.cpp: a C++ host of the handle API, linked against libvda_hip.so (no Python, no torch)."""
+    src = os.path.join(HERE, "..", "examples", "host_demo.cpp")
+    exe = os.path.join(HERE, "host_demo")
+    lib = build()
+    if os.path.exists(exe) and os.path.getmtime(exe) > max(os.path.getmtime(src), os.path.getmtime(lib), _deps_mtime()):
+        return exe
+    cmd = [HIPCC, "-O2", "-std=c++17", src, "-I", os.path.join(HERE, "..", "include"), "-L", HERE, "-lvda_hip",
+           "-Wl,-rpath,$ORIGIN", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"host_demo build failed:\n{r.stderr}")
+    if verbose:
+        print("built", exe)
+    return exe
+
+
 if __name__ == "__main__":
     build(verbose=True)
+    build_host_demo(verbose=True)
