@@ -330,6 +330,35 @@ def test_run_cli_synthetic(tmp_path):
     assert 0 < e < 5e-3, "--fp32 must change the arithmetic (and only slightly)"
 
 
+def test_run_cli_config1_vits_fp32_full_clip(tmp_path):
+    """BASELINE.json configs[0] as far as this product can run it: ViT-S, one 32x518x518 clip, fp32, through run.py. The
+    reference runs that config on the CPU; this engine has no CPU path, so the same CLI call runs the fp32-operand kernels on
+    the MI355X (2 windows) and is checked against the oracle's infer_video_depth on the same frames and weights."""
+    import subprocess
+    import sys
+    from oracle import vda_oracle as O
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    frames = np.random.default_rng(11).integers(0, 256, (32, 518, 518, 3), dtype=np.uint8)
+    src = tmp_path / "clip.npz"
+    np.savez(src, frames=frames, fps=24)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "run.py"), "--input_video", str(src), "--output_dir", str(tmp_path / "out"),
+                        "--encoder", "vits", "--fp32", "--checkpoint", "synthetic", "--save_npz"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = np.load(tmp_path / "out" / "clip_depths.npz")["depths"]
+    assert d.shape == (32, 518, 518) and d.dtype == np.float32
+    # window 0 of a 32-frame video is frames 0..31 and is stitched unscaled (video_depth.py:219-224): the first 22 output
+    # frames must equal the oracle's fp32 forward of those 32 frames (about 30 s of CPU time on the box)
+    cfg = get_config("vits")
+    sd = synthetic_state_dict(cfg, seed=0)
+    x = torch.from_numpy(np.stack([O.preprocess_frame(f, 518) for f in frames]))[None]
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, x)[0, :22].numpy()
+    check_map("run_cli.config1.vits_fp32_518", d[:22], ref, TOL32)
+
+
+
 def test_benchmark_infer_driver(tmp_path):
     """benchmark/infer/infer.py (the reference's second caller, always fp32=True): its per-frame .npy equals
     infer_video_depth(fp32=True) called directly on the same frames with the channel order PRESERVED - the reference hands
