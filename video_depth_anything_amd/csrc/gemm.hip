@@ -308,6 +308,13 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel
     }
+    // 64-wide outputs with many rows (the ViT-S head: 3x3 convs and 1x1s at 64 channels): a 256 x 64 tile does twice the MFMAs
+    // per K-tile barrier of the 128 x 64 one at the same 2 workgroups per CU (80 KiB of LDS). VDA_GEMM_TALL64=0 switches it off (A/B).
+    static const int tall64 = getenv("VDA_GEMM_TALL64") ? atoi(getenv("VDA_GEMM_TALL64")) : 1;
+    if (tall64 && a.N <= 64 && a.M >= 16384 && (g_gemm_variant < 0 || g_gemm_variant == 6)) {
+        g_last_kernel = a.a_mode == VDA_A_DENSE ? "gemm_kernel<256, 64, 0>" : "gemm_kernel<256, 64, 1>";
+        return a.a_mode == VDA_A_DENSE ? launch<256, 64, VDA_A_DENSE>(a, s) : launch<256, 64, VDA_A_CONV3X3>(a, s);
+    }
     g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
                                             : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
     const bool narrow = a.N <= 64;

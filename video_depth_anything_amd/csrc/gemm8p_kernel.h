@@ -66,8 +66,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // kept in registers; only the conv row decomposition (two divisions per piece) is cached.
     const int lrow = lane >> 3;
     const int src_chk = ((lane & 7) ^ ((((wave & 1) << 2) + (lrow >> 1)) & 7)) * 8;     // halves
-    int a_pix[AJ], a_yx[AJ];          // conv: b*H*W, and (oy*stride-1) | (ox*stride-1) << 16
+    // conv: per A piece the element offset of the window's top-left tap (+ the lane's swizzled chunk) and a 9-bit mask of the taps
+    // that fall inside the image. The gather itself is a bounds-checked buffer load: a lane whose tap is padding asks for an
+    // offset past the descriptor's range and the hardware writes zeros into LDS - no zero page, no 64-bit pointer select, and
+    // per K tile the address is one scalar (tap offset + channel slice) added to a lane constant, like the dense operand's.
+    int a_base[AJ], a_mask[AJ];
     int tm0 = 0, tn0 = 0;             // origin of the tile being staged
+    [[maybe_unused]] const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, AMODE == VDA_A_CONV3X3 ? (unsigned)(p.cB * p.cH * p.cW * p.cCin) * 2u : 0u, 0x00020000);
     auto set_sources = [&](int t) {
         const int bm = t / nbn, bn = t - bm * nbn;
         tm0 = bm * BM;
@@ -81,9 +87,15 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 const int hw = p.cHo * p.cWo;
                 const int b = m / hw, rem = m - b * hw;
                 const int oy = rem / p.cWo, ox = rem - oy * p.cWo;
-                a_pix[j] = b * p.cH * p.cW;
-                const int iy0 = ok ? oy * p.cStride - 1 : -20000, ix0 = ox * p.cStride - 1;
-                a_yx[j] = (iy0 & 0xffff) | (ix0 << 16);
+                const int iy0 = oy * p.cStride - 1, ix0 = ox * p.cStride - 1;
+                a_base[j] = ((b * p.cH + iy0) * p.cW + ix0) * p.cCin + src_chk;         // only used for taps the mask admits
+                int vy = 0, vx = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    vy |= ((unsigned)(iy0 + t) < (unsigned)p.cH ? 1 : 0) << (3 * t);     // bit 3*ky: row iy0 + ky is inside
+                    vx |= ((unsigned)(ix0 + t) < (unsigned)p.cW ? 1 : 0) << t;           // bit kx
+                }
+                a_mask[j] = ok ? vx * vy : 0;                                            // bit 3*ky + kx
             }
         }
     };
@@ -119,16 +131,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), abuf + (wave + NW * j) * 1024);
             }
         } else {
-            const int tap = cv_tap, ci0 = cv_ci0;            // set by tap_of(kt) / tap_next()
+            const int tap = cv_tap, ci0 = cv_ci0;            // set by tap_of(kt) / tap_next(): wave-uniform (scalar registers)
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;   // tap / 3 for tap = 0..8
+            const int toff = (ky * p.cW + kx) * p.cCin + ci0, bit = 1 << tap;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = j0 + jj;
-                const int iy = (int)(short)(a_yx[j] & 0xffff) + ky, ix = (a_yx[j] >> 16) + kx;
-                const bool ok = (unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW;
-                const h16* src = ok ? (const h16*)p.A + ((size_t)(a_pix[j] + iy * p.cW + ix) * p.cCin + ci0 + src_chk)
-                                    : (const h16*)p.zero_page + src_chk;
-                glds16(src, abuf + (wave + NW * j) * 1024);
+                const unsigned voff = (a_mask[j] & bit) ? (unsigned)(a_base[j] + toff) * 2u : 0xFFFFFFF0u;   // out of range = zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (VDA_LDS_AS void*)(abuf + (wave + NW * j) * 1024), 16, voff, 0, 0, 0);
             }
         }
     };

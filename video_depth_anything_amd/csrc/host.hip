@@ -760,7 +760,7 @@ extern "C" int vda_create(const vda_config* cfg, vda_model** out) {
         return 2;
     }
     for (int i = 0; i < 4; ++i) h->ocp[i] = pad64(cfg->out_channels[i]);
-    h->Fhp = pad64(cfg->features / 2);
+    h->Fhp = (cfg->features / 2 + 31) / 32 * 32;      // output_conv1's width: only the depth tail (32-channel passes) consumes it
     build_spec(h->cfg, h->spec);
     if (dev_alloc(h, 256, &h->zero_page) != 0 || hipMemset(h->zero_page, 0, 256) != hipSuccess) {
         for (void* p : h->owned) (void)hipFree(p);

@@ -13,7 +13,8 @@ convs with no transpose):
   qkv   fp16 [BT*(P+1), 3D]  attention input, read in place with strides (no head split copy)
   taps  fp16 [BT*P, D] x4    final-norm'd patch tokens, cls dropped by the norm kernel
   head  fp16 NHWC [BT, h, w, Cpad]; channel counts padded to multiples of 64 at pack time
-        (ViT-S: 48->64, 96->128, F/2=32->64) so every GEMM K is a multiple of the 64-wide K step
+        (ViT-S: 48->64, 96->128) so every GEMM K is a multiple of the 64-wide K step; output_conv1 (F/2 wide) feeds only
+        the depth tail, whose passes are 32 channels wide: padded to 32
   temporal residual stream fp32 [BT*hw, C]
 Precision map (default, the reference's autocast path): fp16 operands, fp32 accumulate; LayerNorm/GroupNorm/softmax
 statistics fp32; encoder and temporal residual streams fp32; final 32->1 projection reads fp16, writes fp32.
@@ -96,7 +97,7 @@ class Engine:
 
         D, Fe, oc = cfg.embed_dim, cfg.features, cfg.out_channels
         ocp = [_pad(c) for c in oc]
-        Fh, Fhp = Fe // 2, _pad(Fe // 2)
+        Fh, Fhp = Fe // 2, ops.pad_to(Fe // 2, 32)     # output_conv1's width: only the depth tail (32-channel passes) consumes it
         self.ocp, self.Fhp = ocp, Fhp
         p = "pretrained."
         w["patch.w"] = lin(p + "patch_embed.proj.weight", k_pad=KPATCH)
