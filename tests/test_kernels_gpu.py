@@ -174,7 +174,7 @@ def test_gemm_convtranspose(ops, gemm_variant, k):
 
 
 @pytest.mark.parametrize("stride,relu_in,Cin,Cout,H,W_", [(1, False, 64, 64, 9, 11), (1, True, 128, 256, 12, 7), (2, False, 64, 128, 9, 9),
-                                                        (1, True, 64, 32, 20, 20), (1, True, 64, 64, 83, 79), (1, False, 128, 64, 77, 80)])
+                                                        (1, True, 64, 32, 20, 20), (1, True, 64, 64, 83, 79), (1, False, 128, 64, 77, 80), (1, True, 256, 256, 40, 41)])
 def test_conv3x3(ops, gemm_variant, stride, relu_in, Cin, Cout, H, W_):
     from video_depth_anything_amd import _lib
     B = 3

@@ -285,9 +285,11 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // large-tile kernel; BN picked for the smaller padded width
         const int pad256 = (a.N + 255) / 256 * 256, pad128 = (a.N + 127) / 128 * 128;
         big = pad128 < pad256 ? 128 : 256;
-        // 256 x 256 dense: the 8-phase two-group schedule (tools/gemm_ab.py, in-process A/B: -4..-15 % on every encoder shape and
-        // epilogue); conv A keeps the one-barrier kernel (within +-2 %)
-        if (big == 256 && a.a_mode == VDA_A_DENSE) eight = true;
+        // 256 x 256: the 8-phase two-group schedule (tools/gemm_ab.py, in-process A/B: -4..-15 % on every encoder shape and
+        // epilogue). The conv A operand too since it is gathered by bounds-checked buffer loads (one scalar tap offset per K tile,
+        // no pointer select): +7..10 % over the one-barrier kernel on the head's 256-channel convs (it had been 8-16 % SLOWER with
+        // per-stage address math in its load sections).
+        if (big == 256) eight = true;
     }
     if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
         VDA_REQUIRE(g_gemm_variant < 0, "vda_gemm_f16: the 256-row kernel needs N and ldc to be multiples of 8");
@@ -307,13 +309,6 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             g_last_kernel = name;
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel
-    }
-    // 64-wide outputs with many rows (the ViT-S head: 3x3 convs and 1x1s at 64 channels): a 256 x 64 tile does twice the MFMAs
-    // per K-tile barrier of the 128 x 64 one at the same 2 workgroups per CU (80 KiB of LDS). VDA_GEMM_TALL64=0 switches it off (A/B).
-    static const int tall64 = getenv("VDA_GEMM_TALL64") ? atoi(getenv("VDA_GEMM_TALL64")) : 1;
-    if (tall64 && a.N <= 64 && a.M >= 16384 && (g_gemm_variant < 0 || g_gemm_variant == 6)) {
-        g_last_kernel = a.a_mode == VDA_A_DENSE ? "gemm_kernel<256, 64, 0>" : "gemm_kernel<256, 64, 1>";
-        return a.a_mode == VDA_A_DENSE ? launch<256, 64, VDA_A_DENSE>(a, s) : launch<256, 64, VDA_A_CONV3X3>(a, s);
     }
     g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
                                             : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
