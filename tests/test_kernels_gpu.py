@@ -24,7 +24,8 @@ def ops():
     return o
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5], ids=["auto", "tile128", "tile256x256", "tile256x128", "tile256x256_mfma16", "tile256x128_mfma16", "tile256x256_8phase"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7], ids=["auto", "tile128", "tile256x256", "tile256x128", "tile256x256_mfma16", "tile256x128_mfma16", "tile256x256_8phase",
+                                                     "conv_lds_where_it_applies"])
 def gemm_variant(request, ops):
     """Run every GEMM/conv test under each tile family (the dispatcher normally picks per shape)."""
     from video_depth_anything_amd._lib import lib
@@ -174,7 +175,8 @@ def test_gemm_convtranspose(ops, gemm_variant, k):
 
 
 @pytest.mark.parametrize("stride,relu_in,Cin,Cout,H,W_", [(1, False, 64, 64, 9, 11), (1, True, 128, 256, 12, 7), (2, False, 64, 128, 9, 9),
-                                                        (1, True, 64, 32, 20, 20), (1, True, 64, 64, 83, 79), (1, False, 128, 64, 77, 80), (1, True, 256, 256, 40, 41)])
+                                                        (1, True, 64, 32, 20, 20), (1, True, 64, 64, 83, 79), (1, False, 128, 64, 77, 80), (1, True, 256, 256, 40, 41),
+                                                        (1, False, 192, 64, 37, 37), (1, False, 64, 32, 45, 70)])
 def test_conv3x3(ops, gemm_variant, stride, relu_in, Cin, Cout, H, W_):
     from video_depth_anything_amd import _lib
     B = 3

@@ -200,6 +200,9 @@ int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_dense_bn256_sched(const vda_gemm_args& a, hipStream_t s, int sched);
 
+// conv_lds.hip: patch-in-LDS direct 3x3 convolution for narrow outputs; -1 when the problem is not one it covers
+int vda_conv3x3_lds(const vda_gemm_args& a, hipStream_t s);
+
 static int vda_gemm256s_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
     if (a.a_mode == VDA_A_DENSE) return bn == 256 ? vda_gemm256s_dense_bn256(a, s) : vda_gemm256s_dense_bn128(a, s);
     return bn == 256 ? vda_gemm256s_conv_bn256(a, s) : vda_gemm256s_conv_bn128(a, s);
@@ -265,6 +268,16 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             break;
     }
     hipStream_t s = (hipStream_t)stream;
+    // Narrow-output 3x3 convs (Cout <= 64: the ViT-S head) run as a patch-in-LDS direct convolution instead of an implicit GEMM
+    // (variant 7 forces it, any other explicit variant or VDA_CONV_LDS=0 keeps the GEMM: A/B and cross-checks).
+    static const int conv_lds = getenv("VDA_CONV_LDS") ? atoi(getenv("VDA_CONV_LDS")) : 1;
+    if (a.a_mode == VDA_A_CONV3X3 && ((g_gemm_variant < 0 && conv_lds) || g_gemm_variant == 7)) {
+        const int rc = vda_conv3x3_lds(a, s);
+        if (rc >= 0) {
+            g_last_kernel = a.N <= 32 ? "conv3x3_lds_kernel<1>" : "conv3x3_lds_kernel<2>";
+            return rc;
+        }
+    }
     const bool fits32 = (a.a_mode == VDA_A_DENSE ? (long long)a.M * a.lda : 0ll) + a.K < (1ll << 31) && (long long)a.N * a.K < (1ll << 31);
     VDA_REQUIRE(fits32 || g_gemm_variant == 0 || g_gemm_variant < 0, "vda_gemm_f16: operand too large for the 256-row kernel's 32-bit offsets");
     if (!fits32) {
