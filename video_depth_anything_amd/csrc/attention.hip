@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     // ---- Q fragments (B operand: lane holds Q[query r][16ks + 8h .. +7]), pre-scaled by 1/8 (exact)
     const int q_row = qb * BQ + wave * 32 + r;
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(qb * BQ + wave * 32 < N)) != 0;
     h16x8 qf[4];
     {
         const h16* qp = Qb + (size_t)min(q_row, N - 1) * rs + h * 8;
@@ -106,6 +107,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
         const char* Kt = smem + cur * STAGE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
+        // A wave whose 32 queries all lie past N (the 4th wave of a frame's last query block: 1370 = 10 x 128 + 90) only helps
+        // with the staging and the barriers: its SIMD is left to the other workgroups' waves.
+        if (!wave_active) {
+            cur ^= 1;
+            continue;
+        }
 
         // ---- S^T = K . Q^T for the tile's two 32-key halves
         f32x16 s[2];
