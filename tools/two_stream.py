@@ -12,22 +12,23 @@ enc = sys.argv[1] if len(sys.argv) > 1 else "vitl"
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = get_config(enc)
 sd = synthetic_state_dict(cfg, seed=0)
+NS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 ms = []
-for _ in range(2):
+for _ in range(NS):
     m = VideoDepthAnything(encoder=enc, features=cfg.features, out_channels=list(cfg.out_channels))
     m.load_state_dict(sd); ms.append(m.to("cuda"))
 x = torch.randn(1, T, 3, 518, 518, generator=torch.Generator().manual_seed(0)).cuda()
-st = [torch.cuda.Stream(), torch.cuda.Stream()]
+st = [torch.cuda.Stream() for _ in range(NS)]
 for m in ms:
     for _ in range(2): m.forward(x, fp32=False)
 torch.cuda.synchronize()
 def run(n, two):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(n):
-        for j in range(2 if two else 1):
+        for j in range(NS if two else 1):
             with torch.cuda.stream(st[j]):
                 ms[j].forward(x, fp32=False)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    return n * (2 if two else 1) * T / dt
+    return n * (NS if two else 1) * T / dt
 for rep in range(2):
-    print(enc, "T", T, "one stream %.1f frames/s" % run(10, False), "two streams %.1f frames/s" % run(10, True), flush=True)
+    print(enc, "T", T, "one stream %.1f frames/s" % run(10, False), "%d streams %.1f frames/s" % (NS, run(10, True)), flush=True)

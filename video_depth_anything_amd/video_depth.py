@@ -167,15 +167,20 @@ class VideoDepthAnything:
         recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32, device=dev) for _ in range(NSLOT)] if world > 1 else None
         used = [False] * NSLOT
 
+        def acquire(s):
+            """Before anything of slot s (send[s], recv[s]) is overwritten: its lane waits until the consumer has finished with
+            what the slot held two rounds ago."""
+            if used[s]:
+                lanes[s].wait_event(freed[s])
+            used[s] = True
+
         def window_depth(k, s):
             """Window k on lane s: gather (+ resize to the network size) + normalise (video_depth.py:197-201,
             util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into send[s] [32,H0,W0]."""
             ensure(k)
             lane = lanes[s]
             lane.wait_stream(upload)
-            if used[s]:
-                lane.wait_event(freed[s])                                        # the slot's previous window has been consumed
-            used[s] = True
+            acquire(s)
             with torch.cuda.stream(lane):
                 idx = torch.tensor([slot_of[f] for f in plan[k]], dtype=torch.int32, device=dev)
                 if (H0, W0) == (H, W):
@@ -192,7 +197,9 @@ class VideoDepthAnything:
             ensure(mine[pos + 1] if pos + 1 < len(mine) else None)              # overlaps this window's compute
 
         def exchange(s):
-            """The one exchange of the path (RCCL all-gather over xGMI), issued on the slot's lane behind its window."""
+            """The one exchange of the path (RCCL all-gather over xGMI), issued on the slot's lane behind its window. A rank with
+            no window in this round still takes part, so the slot is acquired here too."""
+            acquire(s)
             with torch.cuda.stream(lanes[s]):
                 h = _all_gather(recv[s], send[s])
                 computed[s].record(lanes[s])
