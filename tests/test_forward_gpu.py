@@ -237,6 +237,54 @@ def test_residual_in_layernorm_matches_the_epilogue_residual():
     assert torch.equal(a, py.forward(x, fp32=False)), "both orchestrations, residual-in-LayerNorm form"
 
 
+def test_steady_state_forward_is_graph_capturable_and_allocation_free():
+    """include/vda.h: after the first forward of a (shape, precision) vda_forward only enqueues kernels on the stream it is
+    given - so it can be captured into a HIP graph, and the replay reproduces the eager result bit for bit."""
+    m, _, _ = model_for("vits", 15)
+    x = torch.randn(1, 4, 3, 70, 84, generator=torch.Generator().manual_seed(76)).cuda()
+    ref = m.forward(x, fp32=False).clone()               # first use: layout, pos-embed, workspace
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        m.forward(x, fp32=False)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.forward(x, fp32=False)
+    x.copy_(torch.randn(1, 4, 3, 70, 84, generator=torch.Generator().manual_seed(77)))     # new input, same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, m.forward(x, fp32=False)) and not torch.equal(out, ref)
+
+
+def test_c_abi_refuses_bad_calls_with_the_reference_wording():
+    import ctypes as C
+    from video_depth_anything_amd._lib import lib
+    m, cfg, _ = model_for("tiny", 2)
+    h = m.engine._h
+    x = torch.zeros(1, 2, 3, 30, 28).cuda()
+    out = torch.zeros(1, 2, 30, 28).cuda()
+    assert lib.vda_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 1, 2, 30, 28, 0, None) != 0
+    assert b"Input image height 30 is not a multiple of patch height 14" in lib.vda_last_error()       # patch_embed.py:73
+    assert lib.vda_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 1, 40, 28, 28, 0, None) != 0
+    assert b"temporal_max_len" in lib.vda_last_error()
+    assert lib.vda_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 1, 2, 28, 28, 7, None) != 0
+    assert b"precision" in lib.vda_last_error()
+    assert lib.vda_workspace_bytes(h, 1, 2, 28, 28, 0) > 0
+    assert lib.vda_set_workspace(h, C.c_void_p(x.data_ptr() + 8), 1 << 20) != 0 and b"256-byte aligned" in lib.vda_last_error()
+    small = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    assert lib.vda_set_workspace(h, C.c_void_p(small.data_ptr()), small.numel()) == 0
+    x = torch.zeros(1, 2, 3, 28, 28).cuda()
+    assert lib.vda_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 1, 2, 28, 28, 0, None) != 0
+    assert b"vda_workspace_bytes" in lib.vda_last_error()                   # too small a block is refused, nothing is launched
+    assert lib.vda_set_workspace(h, None, 0) == 0                           # back to a handle-owned block
+    assert lib.vda_prepare(h, 1, 2, 28, 28, 1) == 0                         # front-loads the fp32 weight pack
+    assert lib.vda_forward(h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), 1, 2, 28, 28, 1, None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and float(out.abs().sum()) > 0
+    with pytest.raises(AssertionError, match="multiple of patch height"):
+        m.forward(torch.zeros(1, 2, 3, 30, 28).cuda(), fp32=False)
+
+
 def test_forward_precision_follows_autocast():
     """A bare model(x) is the reference's nn.Module call: fp32 outside torch.autocast, fp16 operands inside."""
     m, _, _ = model_for("tiny", 1)
