@@ -500,6 +500,10 @@ def test_long_video_equals_per_window_forward_plus_host_stitcher():
     assert e < 5e-4
     np.testing.assert_allclose(d, ref, rtol=5e-3, atol=5e-3)
     assert np.array_equal(d[:22], wins[0][:22]), "window 0 is stitched unscaled"
+    # two windows are in flight on two HIP streams with separate workspace / input / output slots: any sharing mistake between
+    # the lanes would show as run-to-run differences
+    d2, _ = m.infer_video_depth(frames, 24, input_size=518, device="cuda", fp32=False)
+    assert np.array_equal(d, d2), "infer_video_depth must be bitwise reproducible"
 
 
 def test_1024_frame_vitl_video_properties():
