@@ -199,6 +199,8 @@ int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_dense_bn256_sched(const vda_gemm_args& a, hipStream_t s, int sched);
+int vda_gemm8p_dense_bn128(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm8p_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 
 // conv_lds.hip: patch-in-LDS direct 3x3 convolution for narrow outputs; -1 when the problem is not one it covers
 int vda_conv3x3_lds(const vda_gemm_args& a, hipStream_t s);
@@ -293,6 +295,10 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
     if (g_gemm_variant == 2 || g_gemm_variant == 4) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
+    if (g_gemm_variant == 9) {               // 9 = 256x128 8-phase two-group schedule
+        eight = true;
+        big = 128;
+    }
     static const int big_min_n = getenv("VDA_GEMM_BIG_MIN_N") ? atoi(getenv("VDA_GEMM_BIG_MIN_N")) : 192;      // A/B hook
     if (g_gemm_variant < 0 && a.N >= big_min_n && a.M >= 2048) {
         // large-tile kernel; BN picked for the smaller padded width
@@ -302,7 +308,9 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // epilogue). The conv A operand too since it is gathered by bounds-checked buffer loads (one scalar tap offset per K tile,
         // no pointer select): +7..10 % over the one-barrier kernel on the head's 256-channel convs (it had been 8-16 % SLOWER with
         // per-stage address math in its load sections).
-        if (big == 256) eight = true;
+        // 256 x 128 on the same schedule (VDA_GEMM_8P128=0: the one-barrier kernel, A/B)
+        static const int eight128 = getenv("VDA_GEMM_8P128") ? atoi(getenv("VDA_GEMM_8P128")) : 1;
+        if (big == 256 || eight128) eight = true;
     }
     if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
         VDA_REQUIRE(g_gemm_variant < 0, "vda_gemm_f16: the 256-row kernel needs N and ldc to be multiples of 8");
@@ -312,8 +320,10 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         vda_gemm_args a8 = a;
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
-        const int rc = eight ? (a.a_mode == VDA_A_DENSE ? (sched8 ? vda_gemm8p_dense_bn256_sched(a8, s, sched8) : vda_gemm8p_dense_bn256(a8, s)) : vda_gemm8p_conv_bn256(a8, s))
-                             : small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s);
+        const int rc = !eight ? (small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s))
+                       : big == 128 ? (a.a_mode == VDA_A_DENSE ? vda_gemm8p_dense_bn128(a8, s) : vda_gemm8p_conv_bn128(a8, s))
+                       : a.a_mode == VDA_A_DENSE ? (sched8 ? vda_gemm8p_dense_bn256_sched(a8, s, sched8) : vda_gemm8p_dense_bn256(a8, s))
+                                                 : vda_gemm8p_conv_bn256(a8, s);
         if (rc >= 0) {
             // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>
             static thread_local char name[64];

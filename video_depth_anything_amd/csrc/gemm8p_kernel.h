@@ -32,6 +32,12 @@ constexpr int BM = 256;
 constexpr int NW = 8;                 // waves
 constexpr int NT = NW * 64;
 
+// counted wait: everything but the wave's KEEP youngest vector-memory operations (LDS-DMA pieces) has landed
+template <int KEEP>
+__device__ __forceinline__ void vm_wait_keep() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+}
+
 template <int BN, int AMODE, int EPI, int SCHED = 1>
 __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
@@ -41,7 +47,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     constexpr int MH = MI / 2;                       // subtiles per half of the wave's rows (pipeline unit)
     constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;   // 1-KiB DMA pieces per wave
     constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
-    static_assert(BN == 256, "the 8-phase schedule is built for the 256 x 256 tile");
+    static_assert(BN == 256 || BN == 128, "the 8-phase schedule is built for 256 x 256 and 256 x 128 tiles");
+    // 256 x 128 (8 waves as 4 x 2, wave tile 64 x 64): the same phases with half the W pieces (1 / 2 / 2 / 1 per phase instead of
+    // 2 / 2 / 2 / 2); the counted wait of phase 4 leaves A(kt+2) and the first half of W(kt+2) in flight: AJ + WJ/2 pieces.
+    constexpr int WH = WJ / 2;                         // W pieces per half-tile of W rows
     constexpr int A_SLOTS = 3, W_BASE = A_SLOTS * A_BYTES;          // [A0 | A1 | A2 | W0 | W1] = 160 KiB
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,6 +58,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int grp = wave >> 2;                         // wave group: 0 = waves 0..3, 1 = their SIMD partners (rows 128.. of the tile)
 
     // Persistent workgroups: one per CU, each walks tiles round by round. In round r the 32 workgroups of an
     // XCD (equal bid % 8) take 32 CONSECUTIVE tiles (N fastest), so concurrently running tiles share A / W panels
@@ -142,7 +152,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
         }
     };
-    auto stage_w = [&](int kt, char* wbuf, int j0 = 0, int j1 = 4) {
+    auto stage_w = [&](int kt, char* wbuf, int j0 = 0, int j1 = BN / 8 / NW) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int j = j0; j < j1; ++j) {
@@ -184,6 +194,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     char* stg = smem + A_BYTES + wave * 8192;
 
     auto lgkm0 = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
+
     // raw barrier: no vmcnt(0) (LDS-DMA stays in flight across it); the empty asm statements keep LDS accesses on their
     // side of it at IR level (the intrinsic itself is not a memory operation), sched_barrier pins the machine schedule
     auto bar = [&]() {
@@ -256,18 +267,18 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             stage_a(1, 0, smem + A_BYTES);
             stage_a(1, 2, smem + A_BYTES);
             if constexpr (SCHED == 1) {
-                stage_w(1, smem + W_BASE + W_BYTES, 0, 2);          // W rows 128.. of K tile 1 follow in phase 1
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                stage_w(1, smem + W_BASE + W_BYTES, 0, WH);         // the second half of W's rows of K tile 1 follows in phase 1
+                vm_wait_keep<AJ + WH>();
             } else {
                 stage_w(1, smem + W_BASE + W_BYTES);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile 0 landed (mine); K tile 1 stays in flight
+                vm_wait_keep<AJ + WJ>();                                  // K tile 0 landed (mine); K tile 1 stays in flight
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         bar();                                  // ... and everyone's
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 1] = __builtin_readcyclecounter();
-        if (wm == 1) bar();                     // waves 4..7 run one barrier behind from here to the end of the K loop
+        if (grp == 1) bar();                    // waves 4..7 run one barrier behind from here to the end of the K loop
 
         int sa = 0;                             // A slot of K tile kt (kt % 3)
         tap_of(2);                              // conv: (tap, channel slice) of the next K tile to stage, advanced per K tile
@@ -284,7 +295,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 char* wb1 = smem + W_BASE + ((kt + 1) & 1) * W_BYTES;
                 read_w(wb, 0, fw);
                 read_a(ab, 0, 0, fa);
-                if (kt + 1 < nt) stage_w(kt + 1, wb1, 2, 4);
+                if (kt + 1 < nt) stage_w(kt + 1, wb1, WH, WJ);
                 lgkm0();
                 relu_a(fa);
                 bar();
@@ -310,8 +321,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 bar();
                 read_a(ab, 1, 1, fa);
                 if (more) {
-                    stage_w(kt + 2, const_cast<char*>(wb), 0, 2);
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    stage_w(kt + 2, const_cast<char*>(wb), 0, WH);
+                    vm_wait_keep<AJ + WH>();
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -353,7 +364,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 read_a(ab, 1, 1, fa);
                 if (more) {
                     stage_w(kt + 2, const_cast<char*>(wb));
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // K tile kt+1 landed; A(kt+2), W(kt+2) stay in flight
+                    vm_wait_keep<AJ + WJ>();                                  // K tile kt+1 landed; A(kt+2), W(kt+2) stay in flight
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -365,7 +376,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
             sa = sa == 2 ? 0 : sa + 1;
         }
-        if (wm == 0) bar();                     // re-align the two groups: every wave is past its last MFMA section's reads
+        if (grp == 0) bar();                    // re-align the two groups: every wave is past its last MFMA section's reads
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 2] = __builtin_readcyclecounter();
         // Nobody reads the pipeline buffers any more. The NEXT tile's first K tile is issued after the first 32-row block of
         // the epilogue (below): early enough that the rest of the epilogue covers its HBM/L2 latency, late enough that the
