@@ -308,8 +308,9 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // epilogue). The conv A operand too since it is gathered by bounds-checked buffer loads (one scalar tap offset per K tile,
         // no pointer select): +7..10 % over the one-barrier kernel on the head's 256-channel convs (it had been 8-16 % SLOWER with
         // per-stage address math in its load sections).
-        // 256 x 128 on the same schedule (VDA_GEMM_8P128=0: the one-barrier kernel, A/B)
-        static const int eight128 = getenv("VDA_GEMM_8P128") ? atoi(getenv("VDA_GEMM_8P128")) : 1;
+        // 256 x 128 on the same schedule (variant 9 / VDA_GEMM_8P128=1) is built and tested but NOT the default: in-process A/B on
+        // ViT-S's N = 384 / 1152 / 1536 GEMMs (K = 384: six K tiles) and on output_conv1 it is -4..+2 % against the one-barrier kernel
+        static const int eight128 = getenv("VDA_GEMM_8P128") ? atoi(getenv("VDA_GEMM_8P128")) : 0;
         if (big == 256 || eight128) eight = true;
     }
     if (big && (a.N % 8 != 0 || a.ldc % 8 != 0)) {
