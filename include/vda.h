@@ -160,6 +160,12 @@ int vda_pos_embed_resample_f32(const float* pe, float* out, int g, int ph, int p
 /* cls rows of the token matrix: tok[b*(P+1), :] = cls + pos[0] (dinov2.py:218-219). */
 int vda_cls_rows_f32(float* tok, const float* cls, const float* pos, int B, int P, int D, vda_stream_t stream);
 
+/* Input of the head's readout projection when use_clstoken=True (dpt_temporal.py:56-59, dpt.py:129-132): final-norm'd tokens
+ * [frames*(P+1), D] (cls at row 0 of every frame) -> [frames*P, 2D] = cat(patch token, the frame's cls token). The projection itself
+ * (Linear 2D -> D + GELU) is vda_gemm_* with VDA_EPI_BIAS_GELU_F16. */
+int vda_readout_concat_f16(const void* tok, void* out, int frames, int P, int D, vda_stream_t stream);
+int vda_readout_concat_f32(const float* tok, float* out, int frames, int P, int D, vda_stream_t stream);
+
 /* Final 1x1 conv 32->1 + ReLU on NHWC fp16 [rows, Cpad] (first 32 channels used)
  * -> fp32 [rows] (dpt.py:121-122). */
 int vda_head_out_f16_f32(const void* in, const float* w, float bias, float* out, int rows, int Cpad, vda_stream_t stream);
@@ -226,6 +232,7 @@ typedef struct vda_config {
     int32_t features;         /* 64 / 256                                                    run.py:41-42 */
     int32_t out_channels[4];  /* 48,96,192,384 / 256,512,1024,1024 */
     int32_t num_frames;       /* 32: temporal window (pos_encoder.pe rows) */
+    int32_t use_clstoken;     /* 0 (every released config) / 1: head.readout_projects fold the cls token in, dpt.py:92-98 */
 } vda_config;
 
 enum vda_precision {

@@ -93,7 +93,7 @@ def build_reference(cfg, sd, ref_root):
             mlp_ratio=4, block_fn=partial(Block, attn_class=MemEffAttention), init_values=1.0, ffn_layer="mlp",
             block_chunks=0, num_register_tokens=0, interpolate_antialias=False, interpolate_offset=0.1)
     m.head = DPTHeadTemporal(m.pretrained.embed_dim, cfg.features, False, out_channels=list(cfg.out_channels),
-                             use_clstoken=False, num_frames=cfg.num_frames, pe="ape")
+                             use_clstoken=cfg.use_clstoken, num_frames=cfg.num_frames, pe="ape")
     m.load_state_dict(sd, strict=True)
     return m.eval()
 
@@ -225,6 +225,20 @@ def main():
                         depth_mean=float(d.mean()), depth_absmax=float(np.abs(d).max()),
                         row_sums=d.sum(axis=-1).astype(np.float64), sd_seed=0, sd_checksum=sd_checksum(sd))
     print("vits_518", depth.shape, float(depth.mean()))
+
+    # ---- 4b. tiny config with use_clstoken=True (readout projections, dpt_temporal.py:56-59) -----------------------------
+    cfg = get_config("tiny", use_clstoken=True)
+    sd = synthetic_state_dict(cfg, seed=4)
+    model = build_reference(cfg, sd, "/root/reference")
+    x = torch.randn(1, 3, 3, 42, 56, generator=torch.Generator().manual_seed(104))
+    store, hooks = capture_stages(model)
+    with torch.no_grad():
+        depth = model.forward(x)
+    for h in hooks:
+        h.remove()
+    np.savez_compressed(os.path.join(OUT, "tiny_clstoken_forward.npz"), x=x.numpy(), depth=depth.numpy(), layer_1=store["layer_1"].numpy(),
+                        layer_2=store["layer_2"].numpy(), sd_seed=4, sd_checksum=sd_checksum(sd))
+    print("tiny_clstoken_forward", depth.shape, float(depth.mean()))
 
     # ---- 5. stitcher maths directly (utils/util.py) -------------------------------
     from utils.util import compute_scale_and_shift, get_interpolate_frames

@@ -101,8 +101,10 @@ def vit_block(sd: SD, i: int, x: Tensor, num_heads: int) -> Tensor:
 
 
 def encoder_taps(sd: SD, cfg, x: Tensor) -> List[Tensor]:
-    """dinov2.py:271-281,297-321 get_intermediate_layers(norm=True): final LayerNorm
-    on every tap, cls token dropped (the head ignores it, dpt_temporal.py:61)."""
+    """dinov2.py:271-281,297-321 get_intermediate_layers(norm=True, return_class_token=True): final LayerNorm on every tap;
+    the patch tokens, the cls token dropped (use_clstoken=False: the head ignores it, dpt_temporal.py:61) or folded in by the
+    head's readout projection (use_clstoken=True, dpt_temporal.py:56-59 / dpt.py:92-98,129-132):
+    x = GELU(Linear_{2D->D}(cat(patch_tokens, cls broadcast over the patches)))."""
     t = patch_tokens(sd, x)
     D = t.shape[-1]
     taps = []
@@ -110,7 +112,12 @@ def encoder_taps(sd: SD, cfg, x: Tensor) -> List[Tensor]:
         t = vit_block(sd, i, t, cfg.num_heads)
         if i in cfg.taps:
             n = F.layer_norm(t, (D,), sd["pretrained.norm.weight"], sd["pretrained.norm.bias"], 1e-6)
-            taps.append(n[:, 1:])
+            tok, cls = n[:, 1:], n[:, 0]
+            if getattr(cfg, "use_clstoken", False):
+                k = f"head.readout_projects.{len(taps)}.0."
+                readout = cls.unsqueeze(1).expand_as(tok)
+                tok = F.gelu(F.linear(torch.cat((tok, readout), -1), sd[k + "weight"], sd[k + "bias"]))
+            taps.append(tok)
     return taps
 
 

@@ -111,6 +111,32 @@ def test_golden_tiny_every_stage(golden_dir, fp32):
 
 
 @pytest.mark.parametrize("fp32", PRECISIONS)
+def test_golden_tiny_with_clstoken_readout(golden_dir, fp32):
+    """use_clstoken=True (dpt_temporal.py:56-59; no released config sets it): reference-generated golden, both precisions, and
+    the two launch sequences bit-identical on it."""
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import VideoDepthAnything
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    z = np.load(os.path.join(golden_dir, "tiny_clstoken_forward.npz"))
+    cfg = get_config("tiny", use_clstoken=True)
+    m = VideoDepthAnything(encoder="tiny", features=cfg.features, out_channels=list(cfg.out_channels), use_clstoken=True)
+    assert m.cfg.use_clstoken
+    m.load_state_dict(synthetic_state_dict(cfg, seed=int(z["sd_seed"])), strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    d = m.forward(x, fp32=fp32)
+    BT = x.shape[0] * x.shape[1]
+    tag = "tiny_cls.f32." if fp32 else "tiny_cls."
+    for k, C in (("layer_1", cfg.out_channels[0]), ("layer_2", cfg.out_channels[1])):
+        t, h, w, Cp = m.engine.stage(k)
+        check_map(tag + k, nhwc_to_nchw(t, BT, h, w, Cp, C), z[k], tol_of("tiny.stage", fp32), tail=False)
+    check_map(tag + "depth", d.cpu().numpy(), z["depth"], tol_of("tiny.depth", fp32))
+    assert torch.equal(d, m.python_engine().forward(x, fp32=fp32))
+    with pytest.raises(RuntimeError, match="Missing key"):          # the readout weights are part of the strict inventory
+        m.load_state_dict(synthetic_state_dict(get_config("tiny"), seed=1), strict=True)
+
+
+@pytest.mark.parametrize("fp32", PRECISIONS)
 def test_golden_vits_nonsquare(golden_dir, fp32):
     z = np.load(os.path.join(golden_dir, "vits_forward.npz"))
     m, _, _ = model_for("vits", int(z["sd_seed"]))

@@ -322,6 +322,17 @@ def test_bilinear_plane_and_identity(ops):
     assert torch.equal(out.cpu(), x), "identity resize must be exact"
 
 
+@pytest.mark.parametrize("dtype", [F16, F32], ids=["f16", "f32"])
+def test_readout_concat(ops, dtype):
+    frames, P, D = 3, 7, 128
+    tok = rnd(frames * (P + 1), D, seed=95).to(dtype)
+    out = torch.full((frames * P, 2 * D), float("nan"), dtype=dtype, device="cuda")
+    ops.readout_concat(dev(tok), out, frames, P, D)
+    t = tok.reshape(frames, P + 1, D)
+    ref = torch.cat((t[:, 1:], t[:, :1].expand(-1, P, -1)), dim=-1).reshape(frames * P, 2 * D)
+    assert torch.equal(out.cpu(), ref)
+
+
 def test_head_out_and_normalize(ops):
     rows, Cp = 1000, 64
     x = rnd(rows, Cp, seed=49).to(F16)

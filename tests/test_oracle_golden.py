@@ -104,3 +104,16 @@ def test_golden_recipe_reproduces_the_committed_fixtures(flags):
                        capture_output=True, text=True, timeout=600, cwd=repo)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "check ok" in r.stdout
+
+
+def test_tiny_forward_with_clstoken_readout(golden_dir):
+    """use_clstoken=True (dpt_temporal.py:56-59, dpt.py:92-98,129-132): the readout projections over [patch tokens, cls]."""
+    z = load(golden_dir, "tiny_clstoken_forward.npz")
+    cfg = get_config("tiny", use_clstoken=True)
+    sd = seeded_sd(cfg, z)
+    assert "head.readout_projects.3.0.weight" in sd and tuple(sd["head.readout_projects.0.0.weight"].shape) == (128, 256)
+    stages = {}
+    with torch.no_grad():
+        d = O.forward(sd, cfg, torch.from_numpy(z["x"]), stages)
+    assert rel_err(stages["layer_1"].numpy(), z["layer_1"]) < RTOL and rel_err(stages["layer_2"].numpy(), z["layer_2"]) < RTOL
+    assert rel_err(d.numpy(), z["depth"]) < RTOL

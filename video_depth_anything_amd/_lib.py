@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
 class Config(C.Structure):
     """vda_config (include/vda.h)."""
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("taps", C.c_int32 * 4),
-                ("features", C.c_int32), ("out_channels", C.c_int32 * 4), ("num_frames", C.c_int32)]
+                ("features", C.c_int32), ("out_channels", C.c_int32 * 4), ("num_frames", C.c_int32), ("use_clstoken", C.c_int32)]
 
 
 PREC_F16, PREC_F32 = 0, 1
@@ -60,6 +60,8 @@ SIGNATURES = {
     "vda_patchify_f32_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_pos_embed_resample_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_cls_rows_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "vda_readout_concat_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "vda_readout_concat_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_head_out_f16_f32": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
     "vda_head_out_f32_f32": (_i, [_vp, _vp, _f, _vp, _ll, _i, _vp]),
     "vda_depth_tail_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

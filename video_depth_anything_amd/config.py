@@ -40,6 +40,7 @@ class ModelConfig:
     out_channels: Tuple[int, int, int, int]
     num_frames: int = 32
     mlp_ratio: int = 4
+    use_clstoken: bool = False        # dpt.py:92-98,129-132: readout_projects (Linear 2D -> D + GELU over [patch, cls])
 
     @property
     def head_dim(self) -> int:
@@ -56,7 +57,7 @@ _CONFIGS = {
 }
 
 
-def get_config(encoder: str, features: int = None, out_channels=None, num_frames: int = 32) -> ModelConfig:
+def get_config(encoder: str, features: int = None, out_channels=None, num_frames: int = 32, use_clstoken: bool = False) -> ModelConfig:
     if encoder not in _CONFIGS:
         raise KeyError(encoder)
     base = _CONFIGS[encoder]
@@ -64,5 +65,5 @@ def get_config(encoder: str, features: int = None, out_channels=None, num_frames
         base.name, base.embed_dim, base.depth, base.num_heads, base.taps,
         base.features if features is None else int(features),
         base.out_channels if out_channels is None else tuple(int(c) for c in out_channels),
-        num_frames,
+        num_frames, base.mlp_ratio, bool(use_clstoken),
     )

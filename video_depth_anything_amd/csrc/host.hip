@@ -192,6 +192,11 @@ void build_spec(const vda_config& c, Spec& s) {
     put(h + "resize_layers.1.bias", {oc[1]});
     put(h + "resize_layers.3.weight", {oc[3], oc[3], 3, 3});
     put(h + "resize_layers.3.bias", {oc[3]});
+    if (c.use_clstoken)                                             // dpt.py:92-98
+        for (int i = 0; i < 4; ++i) {
+            put(h + "readout_projects." + std::to_string(i) + ".0.weight", {D, 2 * D});
+            put(h + "readout_projects." + std::to_string(i) + ".0.bias", {D});
+        }
     const std::string sc = h + "scratch.";
     for (int i = 0; i < 4; ++i) put(sc + "layer" + std::to_string(i + 1) + "_rn.weight", {F, oc[i], 3, 3});
     for (int i = 1; i <= 4; ++i) {
@@ -322,6 +327,12 @@ int pack_all(vda_model* h, int prec) {
     VDA_TRY(vecp("norm.w", p + "norm.weight", D, D));
     VDA_TRY(vecp("norm.b", p + "norm.bias", D, D));
     const std::string hd = "head.";
+    if (c.use_clstoken)
+        for (int i = 0; i < 4; ++i) {
+            const std::string n = hd + "readout_projects." + std::to_string(i) + ".0", k = "readout" + std::to_string(i);
+            VDA_TRY(lin(k + ".w", n + ".weight", D, 2 * D, D, 2 * D));
+            VDA_TRY(vecp(k + ".b", n + ".bias", D, D));
+        }
     for (int i = 0; i < 4; ++i) {
         const std::string n = hd + "projects." + std::to_string(i), k = "proj" + std::to_string(i);
         VDA_TRY(lin(k + ".w", n + ".weight", oc[i], D, ocp[i], D));
@@ -633,7 +644,21 @@ struct Run {
                 VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, 4 * D, V(k + "mlp.fc2.bias"), tok, V(k + "ls2.gamma")));
                 if (tp != nullptr) VDA_TRY(layernorm(tok, tp, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, Nt, 1));     // final norm, cls dropped
             }
-            if (tp != nullptr) taps[ntap++] = tp;
+            if (tp != nullptr) {
+                if (c.use_clstoken) {
+                    // dpt_temporal.py:56-59: the tap becomes GELU(Linear([patch token, cls])); the final norm above dropped the cls
+                    // row, so norm the whole token matrix again (cls kept) and gather [patch | cls] rows for one K = 2D GEMM
+                    void* full = act("rd_full", (size_t)rows * D);
+                    VDA_TRY(layernorm(tok, full, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D));
+                    void* cat = act("rd_cat", (size_t)BT * P * 2 * D);
+                    if (!dry)
+                        VDA_TRY(prec == VDA_PREC_F32 ? vda_readout_concat_f32((const float*)full, (float*)cat, BT, P, D, s)
+                                                     : vda_readout_concat_f16(full, cat, BT, P, D, s));
+                    const std::string kr = "readout" + std::to_string(ntap);
+                    VDA_TRY(dense(cat, W(kr + ".w"), tp, VDA_EPI_BIAS_GELU_F16, BT * P, D, 2 * D, V(kr + ".b")));
+                }
+                taps[ntap++] = tp;
+            }
         }
         if (ntap != 4) {
             vda_set_error("vda_forward: the configuration's taps are not four distinct block indices below depth");

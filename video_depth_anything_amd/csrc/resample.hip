@@ -232,6 +232,23 @@ __global__ void __launch_bounds__(256) pos_embed_resample_kernel(const float* __
     }
 }
 
+// Readout input of the use_clstoken head (dpt_temporal.py:56-59): tokens [frames*(P+1), D] with the cls token at row 0 of every
+// frame -> [frames*P, 2D] = cat(patch token, that frame's cls token). 8 elements per lane.
+template <typename T>
+__global__ void __launch_bounds__(256) readout_concat_kernel(const T* __restrict__ tok, T* __restrict__ out, int frames, int P, int D) {
+    const int nv = D >> 3;
+    const size_t total = (size_t)frames * P * 2 * nv;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int v = (int)(i % (2 * nv));
+        const size_t r = i / (2 * nv);
+        const int f = (int)(r / P), p = (int)(r - (size_t)f * P);
+        const T* src = v < nv ? tok + ((size_t)f * (P + 1) + 1 + p) * D + v * 8 : tok + (size_t)f * (P + 1) * D + (v - nv) * 8;
+        float x[8];
+        load8(src, x);
+        store8(out + r * 2 * D + (size_t)v * 8, x);
+    }
+}
+
 inline unsigned capped_grid(size_t work_items) {
     size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 16;
@@ -349,4 +366,22 @@ extern "C" int vda_pos_embed_resample_f32(const float* pe, float* out, int g, in
                        g, ph, pw, D, inv_sy, inv_sx);
     VDA_LAUNCH_CHECK();
     return 0;
+}
+
+template <typename T>
+static int readout_concat_launch(const T* tok, T* out, int frames, int P, int D, vda_stream_t stream) {
+    VDA_REQUIRE(tok && out && frames > 0 && P > 0 && D > 0 && D % 8 == 0, "vda_readout_concat: bad arguments");
+    VDA_REQUIRE(((uintptr_t)tok & 15) == 0 && ((uintptr_t)out & 15) == 0, "vda_readout_concat: 16-byte alignment required");
+    hipLaunchKernelGGL((readout_concat_kernel<T>), dim3(capped_grid((size_t)frames * P * 2 * (D / 8))), dim3(256), 0, (hipStream_t)stream, tok, out,
+                       frames, P, D);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_readout_concat_f16(const void* tok, void* out, int frames, int P, int D, vda_stream_t stream) {
+    return readout_concat_launch<h16>((const h16*)tok, (h16*)out, frames, P, D, stream);
+}
+
+extern "C" int vda_readout_concat_f32(const float* tok, float* out, int frames, int P, int D, vda_stream_t stream) {
+    return readout_concat_launch<float>(tok, out, frames, P, D, stream);
 }

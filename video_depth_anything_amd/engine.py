@@ -113,6 +113,10 @@ class Engine:
         w["norm.w"], w["norm.b"] = f32(p + "norm.weight"), f32(p + "norm.bias")
 
         h = "head."
+        if cfg.use_clstoken:                                     # dpt.py:92-98: Linear(2D -> D) + GELU per tap
+            for i in range(4):
+                w[f"readout{i}.w"] = lin(f"{h}readout_projects.{i}.0.weight")
+                w[f"readout{i}.b"] = f32(f"{h}readout_projects.{i}.0.bias")
         for i in range(4):
             w[f"proj{i}.w"] = lin(f"{h}projects.{i}.weight", n_pad=ocp[i])
             w[f"proj{i}.b"] = padvec(f"{h}projects.{i}.bias", ocp[i])
@@ -328,6 +332,15 @@ class Engine:
                 if tp is not None:
                     ops.layernorm(tok, tp, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D, group=Nt, skip=1)
             if tp is not None:
+                if cfg.use_clstoken:
+                    # dpt_temporal.py:56-59: the tap becomes GELU(Linear([patch token, cls])); the final norm above dropped the cls
+                    # row, so norm the whole token matrix again (cls kept) and gather [patch | cls] rows for one K = 2D GEMM
+                    full = self.buf("rd_full", (rows, D), self.act)
+                    ops.layernorm(tok, full, w["norm.w"], w["norm.b"], ENC_LN_EPS, rows, D)
+                    cat = self.buf("rd_cat", (BT * P, 2 * D), self.act)
+                    ops.readout_concat(full, cat, BT, P, D)
+                    j = len(taps)
+                    ops.gemm(cat, w[f"readout{j}.w"], tp, _lib.EPI_BIAS_GELU_F16, M=BT * P, N=D, K=2 * D, bias=w[f"readout{j}.b"])
                 taps.append(tp)
         if taps_out is not None:
             taps_out.extend(taps)

@@ -194,6 +194,15 @@ def cls_rows(tok, cls, pos, B, P, D):
     check(lib.vda_cls_rows_f32(_p(tok), _p(cls), _p(pos), B, P, D, _stream(tok)), "vda_cls_rows_f32")
 
 
+def readout_concat(tok, out, frames, P, D):
+    """[frames*(P+1), D] (cls first) -> [frames*P, 2D] = cat(patch token, the frame's cls token)."""
+    _act(tok, "tok"), _req(out, tok.dtype, "out")
+    if tok.numel() < frames * (P + 1) * D or out.numel() < frames * P * 2 * D:
+        raise ValueError("readout_concat buffers too small")
+    fn = lib.vda_readout_concat_f32 if tok.dtype == F32 else lib.vda_readout_concat_f16
+    check(fn(_p(tok), _p(out), frames, P, D, _stream(tok)), "vda_readout_concat")
+
+
 def head_out(x, w, bias, out, rows, Cpad):
     _act(x, "x"), _req(w, F32, "w"), _req(out, F32, "out")
     fn = lib.vda_head_out_f32_f32 if x.dtype == F32 else lib.vda_head_out_f16_f32

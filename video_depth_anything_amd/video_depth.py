@@ -37,11 +37,11 @@ class VideoDepthAnything:
     def __init__(self, encoder='vits', features=64, out_channels=[48, 96, 192, 384], use_bn=False, use_clstoken=False,
                  num_frames=32, pe='ape', **_unused):
         # num_block / out_channel / conv of the fork's constructor (video_depth.py:47-49) are accepted and unused, as there.
-        if use_bn or use_clstoken or pe != 'ape':
-            raise NotImplementedError("only the released configuration (use_bn=False, use_clstoken=False, pe='ape') is built")
+        if use_bn or pe != 'ape':
+            raise NotImplementedError("use_bn=True and pe != 'ape' are not built (no released configuration uses them)")
         self.encoder = encoder
         self.intermediate_layer_idx = {'vits': [2, 5, 8, 11], 'vitl': [4, 11, 17, 23]}
-        self.cfg = get_config(encoder, features, out_channels, num_frames)
+        self.cfg = get_config(encoder, features, out_channels, num_frames, use_clstoken)
         self.engine = None
         self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self._sd = None

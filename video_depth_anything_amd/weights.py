@@ -5,7 +5,7 @@ The flat fp32 state dict is the one `run.py` hands to `load_state_dict(strict=Tr
 (/root/reference/run.py:46). Key inventory follows the modules that own the
 parameters:
   pretrained.*            /root/reference/video_depth_anything/dinov2.py:106-168
-  head.projects/resize    /root/reference/video_depth_anything/dpt.py:60-90
+  head.projects/resize    /root/reference/video_depth_anything/dpt.py:60-98 (readout_projects when use_clstoken)
   head.scratch.*          /root/reference/video_depth_anything/util/blocks.py:20-32,52-58,124-129
                           /root/reference/video_depth_anything/dpt.py:117-124
   head.motion_modules.*   /root/reference/video_depth_anything/motion_module/motion_module.py:84-100,141-161,194
@@ -65,6 +65,10 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
     s[h + "resize_layers.1.bias"] = (oc[1],)
     s[h + "resize_layers.3.weight"] = (oc[3], oc[3], 3, 3)
     s[h + "resize_layers.3.bias"] = (oc[3],)
+    if cfg.use_clstoken:                                     # dpt.py:92-98
+        for i in range(4):
+            s[f"{h}readout_projects.{i}.0.weight"] = (D, 2 * D)
+            s[f"{h}readout_projects.{i}.0.bias"] = (D,)
     sc = h + "scratch."
     for i in range(4):
         s[f"{sc}layer{i + 1}_rn.weight"] = (F_, oc[i], 3, 3)
