@@ -44,3 +44,18 @@ def test_max_res_and_depth_visualisation(tmp_path):
     p = save_video(depth, str(tmp_path / "d_vis.mp4"), fps=5, is_depths=True)
     g = save_video(depth, str(tmp_path / "g_vis.mp4"), fps=5, is_depths=True, grayscale=True)
     assert os.path.exists(p) and os.path.exists(g)
+
+
+def test_npy_is_memory_mapped_until_a_window_reads_it(tmp_path):
+    """A .npy video stays on disk: read_video_frames returns a memory map (no stride, no down-scaling), a strided or
+    down-scaled read materialises it like the reference's decoders do."""
+    f = _frames(9)
+    np.save(tmp_path / "v.npy", f)
+    out, fps = read_video_frames(str(tmp_path / "v.npy"), -1)
+    assert isinstance(out, np.memmap) and out.shape == f.shape and fps == 24.0 and np.array_equal(out, f)
+    out, _ = read_video_frames(str(tmp_path / "v.npy"), 5)
+    assert isinstance(out, np.memmap) and np.array_equal(out, f[:5])
+    out, _ = read_video_frames(str(tmp_path / "v.npy"), -1, target_fps=12)
+    assert not isinstance(out, np.memmap) and np.array_equal(out, f[::2])
+    out, _ = read_video_frames(str(tmp_path / "v.npy"), -1, max_res=10)
+    assert not isinstance(out, np.memmap) and max(out.shape[1:3]) == 10

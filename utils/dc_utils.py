@@ -37,7 +37,9 @@ def _decode(video_path):
                   for n in names]
         return np.stack(frames), 24.0
     if ext == ".npy":
-        return np.load(video_path), 24.0
+        # memory-mapped: frames are paged in when infer_video_depth uploads the windows that read them, so a long video is never
+        # held in RAM as one array (the reference's decoders return the whole video, dc_utils.py:19-69)
+        return np.load(video_path, mmap_mode="r"), 24.0
     if ext == ".npz":
         z = np.load(video_path)
         return z["frames"], float(z["fps"]) if "fps" in z else 24.0
@@ -74,15 +76,19 @@ def read_video_frames(video_path, process_length, target_fps=-1, max_res=-1):
     """dc_utils.py:18-70: every `stride`-th frame (stride = max(round(src_fps / fps), 1)), at most `process_length`
     frames read, frames larger than `max_res` scaled down. Returns (uint8 [N,H,W,3], fps)."""
     frames, src_fps = _decode(video_path)
-    frames = np.asarray(frames)
+    if not isinstance(frames, np.ndarray):
+        frames = np.asarray(frames)
     if frames.ndim != 4 or frames.shape[-1] != 3:
         raise ValueError(f"expected frames [N,H,W,3], got {frames.shape}")
     fps = src_fps if target_fps < 0 else target_fps
     stride = max(round(src_fps / fps), 1)
     if process_length > 0:
         frames = frames[:process_length]              # the cv2 branch counts SOURCE frames (dc_utils.py:57)
-    frames = np.ascontiguousarray(frames[::stride], dtype=np.uint8)
     h, w = frames.shape[1:3]
+    lazy = isinstance(frames, np.memmap) and stride == 1 and frames.dtype == np.uint8 and not (max_res > 0 and max(h, w) > max_res)
+    if lazy:
+        return frames, fps                            # still on disk: infer_video_depth pages in what each window reads
+    frames = np.ascontiguousarray(frames[::stride], dtype=np.uint8)
     if max_res > 0 and max(h, w) > max_res:
         scale = max_res / max(h, w)
         frames = _resize_bilinear(frames, round(h * scale), round(w * scale))

@@ -115,7 +115,8 @@ class VideoDepthAnything:
         from . import ops
         from .scheduler import drive_windows, plan_windows, shard_windows
         from .stitch import stitch_stream
-        frames = np.asarray(frames)
+        if not isinstance(frames, np.ndarray):
+            frames = np.asarray(frames)
         if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
             frames = np.ascontiguousarray(frames).astype(np.uint8)
         H0, W0 = frames.shape[1:3]
@@ -130,8 +131,7 @@ class VideoDepthAnything:
         # The uint8 frames THIS rank's windows read (frame 0, the previous window's key frame and its own 30 frames each -
         # SURVEY.md section 8e) live in HBM in a compact buffer, and each crosses PCIe once - not all up front: what the next
         # window needs is uploaded on a side stream while the current one computes.
-        frames = np.ascontiguousarray(frames)
-        host = torch.from_numpy(frames)
+        # `frames` may be a memory map (utils/dc_utils.read_video_frames on a .npy): only the runs a window needs are touched
         need = sorted({f for k in mine for f in plan[k]})
         slot_of = {f: i for i, f in enumerate(need)}
         video = torch.empty((max(len(need), 1), H0, W0, 3), dtype=torch.uint8, device=dev)
@@ -151,7 +151,10 @@ class VideoDepthAnything:
                     while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1:
                         j += 1
                     s0 = slot_of[todo[i]]
-                    video[s0:s0 + (j - i + 1)].copy_(host[todo[i]:todo[j] + 1], non_blocking=True)
+                    run = frames[todo[i]:todo[j] + 1]
+                    if not (run.flags.c_contiguous and run.flags.writeable):
+                        run = np.array(run)                  # a memory-mapped or strided source: page this run in
+                    video[s0:s0 + (j - i + 1)].copy_(torch.from_numpy(run), non_blocking=True)
                     i = j + 1
             resident.update(todo)
 
