@@ -532,6 +532,20 @@ def test_long_video_equals_per_window_forward_plus_host_stitcher():
     assert np.array_equal(d, d2), "infer_video_depth must be bitwise reproducible"
 
 
+def test_memory_mapped_video_equals_in_memory_video(tmp_path):
+    """utils/dc_utils.read_video_frames hands a .npy video over as a memory map; infer_video_depth pages in the runs each window
+    reads and must return exactly what it returns for the same frames held in RAM."""
+    from utils.dc_utils import read_video_frames
+    m, _, _ = model_for("tiny", 6)
+    frames = np.random.default_rng(34).integers(0, 256, (70, 42, 56, 3), dtype=np.uint8)
+    np.save(tmp_path / "v.npy", frames)
+    lazy, fps = read_video_frames(str(tmp_path / "v.npy"), -1)
+    assert isinstance(lazy, np.memmap)
+    a, _ = m.infer_video_depth(lazy, fps, input_size=42, device="cuda")
+    b, _ = m.infer_video_depth(frames, fps, input_size=42, device="cuda")
+    assert a.shape == (70, 42, 56) and np.array_equal(a, b)
+
+
 def test_1024_frame_vitl_video_properties():
     """BASELINE.json config 4's single-GPU content: ViT-L, 1024 frames of 518x518 = 47 windows through infer_video_depth."""
     m, _, _ = model_for("vitl", 0)

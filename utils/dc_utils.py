@@ -20,7 +20,7 @@ IMAGE_EXT = (".png", ".jpg", ".jpeg", ".bmp", ".tif", ".tiff", ".webp")
 
 def _resize_bilinear(frames, height, width):
     import torch
-    x = torch.from_numpy(frames).permute(0, 3, 1, 2).float()
+    x = torch.from_numpy(np.array(frames)).permute(0, 3, 1, 2).float()       # a copy: the source may be a read-only memory map
     y = torch.nn.functional.interpolate(x, size=(height, width), mode="bilinear", align_corners=False, antialias=False)
     return y.round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy()
 
