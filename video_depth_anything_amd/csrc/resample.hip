@@ -30,8 +30,12 @@ __global__ void __launch_bounds__(256) bilinear_nhwc_kernel(const T* __restrict_
     const size_t orow = ((size_t)b * H + Y) * W * C;
     const float xscale = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const int n = W * nv;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int X = i / nv, v = i - X * nv;
+    // thread -> (X, 8-channel vector): when 256 % nv == 0 a thread keeps its vector v and walks X with a constant step (no
+    // per-item division; consecutive lanes still cover consecutive vectors of a pixel: 16-byte coalesced), else the flat index
+    const bool fixed_v = (256 % nv) == 0;
+    const int v_fixed = threadIdx.x % nv, x_first = threadIdx.x / nv, x_step = 256 / nv;
+    for (int i = threadIdx.x, Xw = x_first; i < n; i += 256, Xw += x_step) {
+        const int X = fixed_v ? Xw : i / nv, v = fixed_v ? v_fixed : i - X * nv;
         const float src = xscale * (float)X;
         const int x0 = min((int)src, w - 1), x1 = min(x0 + 1, w - 1);
         const float wx = src - (float)x0;
