@@ -581,3 +581,21 @@ def test_ranks_share_one_gpu(tmp_path):
         assert d.shape == single.shape == (100, 28, 42)
         assert np.array_equal(d, single), f"rank {rank} differs from the single-rank result"
     assert open(f"{out}_result_ranks.txt").read() == "rank0:array rank1:None rank2:None"
+
+
+def test_bench_two_ranks_rehearsal(tmp_path):
+    """bench.py's multi-rank flow (rank env, barrier, per-step exchange, max-over-ranks time, one JSON line from rank 0) with 2 ranks
+    sharing this GPU over gloo (VDA_BENCH_BACKEND=gloo: a rehearsal mode, never a measurement; RCCL itself only runs on the driver's
+    multi-GPU node). ViT-S keeps it short."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VDA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29761",
+           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--encoder", "vits", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["world"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
