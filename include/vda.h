@@ -54,7 +54,16 @@ enum vda_epilogue {
     VDA_EPI_PATCH_F32 = 6,       /* out_f[(m/P)*(P+1) + 1 + m%P, n] = acc + bias[n] + pos[(1 + m%P)*N + n]   dinov2.py:218-219 */
     VDA_EPI_CONVT_F16 = 7,       /* W rows ordered (ky,kx,co): pixel-shuffle scatter of a k==stride ConvTranspose2d  dpt.py:71-82 */
     VDA_EPI_BIAS_F32 = 8,        /* out_f[m,n] = acc + bias[n] */
-    VDA_EPI_SCALE_RES_F32_H = 9  /* out_h[m,n] = (fp16)(res_f[m,n] + gamma[n]*(acc + bias[n])): leaves an fp32 residual stream */
+    VDA_EPI_SCALE_RES_F32_H = 9, /* out_h[m,n] = (fp16)(res_f[m,n] + gamma[n]*(acc + bias[n])): leaves an fp32 residual stream */
+    /* ---- LayerNorm folded into the GEMMs either side of it (block.py:105-106 + :56/:68 of the next sub-block), fp16 path only.
+     * The fp32 residual stream x is kept as TWO fp16 planes, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22+ significant
+     * bits): the hi plane IS the A operand of the GEMM that consumes LayerNorm(x), so no LayerNorm pass touches memory. */
+    VDA_EPI_SCALE_RES_SPLIT = 10,/* x' = (res_h + res2_h) + gamma[n]*(acc + bias[n]); out_h = fp16(x'), out2_h = fp16(x' - out_h) (in place
+                                    over res / res2 is allowed); stats[m, n/64, :] = (sum, centred sum of squares) of x' over the 64
+                                    columns n/64*64.. (fp32; N % 64 == 0): vda_ln_stats_finalize turns them into (mean, rstd) rows */
+    VDA_EPI_LN_BIAS_F16 = 11,    /* A = hi plane, W = W*diag(ln_w) (vda_fold_ln_weight): out_h = rstd[m]*(acc - mean[m]*gamma[n]) + bias[n]
+                                    with (mean, rstd) = stats[m, 0:2], gamma = c1 = row sums of the folded W, bias = c2 = b + W.ln_b */
+    VDA_EPI_LN_GELU_F16 = 12     /* the same followed by gelu_erf (mlp.fc1) */
 };
 
 typedef struct vda_gemm_args {
@@ -75,6 +84,9 @@ typedef struct vda_gemm_args {
     int32_t cB, cH, cW, cCin, cHo, cWo, cStride;
     /* VDA_EPI_PATCH_F32: P patches per frame. VDA_EPI_CONVT_F16: k, input h, w, Cout */
     int32_t P, tK, tH, tW, tCout;
+    void* out2;             /* VDA_EPI_SCALE_RES_SPLIT: lo plane of the result */
+    float* stats;           /* VDA_EPI_SCALE_RES_SPLIT: out, [M, N/64, 2] partial row statistics (may be NULL);
+                               VDA_EPI_LN_*: in, [M, 2] (mean, rstd) */
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
@@ -110,6 +122,21 @@ int vda_layernorm_residual_f32_f16(float* x, const void* y, const float* gamma, 
 int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const float* b, float eps,
                           int rows, int D, int group, int skip,
                           const float* pe, int pe_rows_per_step, int pe_steps, vda_stream_t stream);
+
+/* ---- LayerNorm folded into the neighbouring GEMMs (VDA_EPI_SCALE_RES_SPLIT / VDA_EPI_LN_*; block.py:56,68,105-106)
+ * vda_split_stats_f32: fp32 rows x [rows, D] -> the two fp16 planes (hi = fp16(x), lo = fp16(x - hi)) and the row statistics
+ *   stat[r] = (mean, rstd = 1/sqrt(var + eps)) (two-pass, fp32): the entry into the split stream after the patch embedding.
+ * vda_ln_stats_finalize: partial[r, np, 2] (sum, centred sum of squares per 64 columns, as VDA_EPI_SCALE_RES_SPLIT writes them)
+ *   -> stat[r] = (mean, rstd), combined in column order (Chan et al.), D = 64*np.
+ * vda_layernorm_split_f16: LayerNorm of x = hi + lo (fp32 statistics), fp16 out, group/skip as vda_layernorm_f32_f16 (the taps).
+ * vda_fold_ln_weight: pack-time fold of LayerNorm's affine into the Linear that follows it: Wf[n,k] = fp16(W[n,k]*ln_w[k]),
+ *   c1[n] = sum_k Wf[n,k] (of the ROUNDED values, fp32), c2[n] = b[n] + sum_k W[n,k]*ln_b[k] (fp32; b may be NULL). */
+int vda_split_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream);
+int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, vda_stream_t stream);
+int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const float* w, const float* b, float eps,
+                            int rows, int D, int group, int skip, vda_stream_t stream);
+int vda_fold_ln_weight(const float* W, const float* bias, const float* ln_w, const float* ln_b, void* Wf, float* c1, float* c2,
+                       int N, int K, vda_stream_t stream);
 
 /* GroupNorm(32 groups) per frame on NHWC fp16 [frames, hw, C] -> fp16 [frames*hw, C]
  * (motion_module.py:84,110). `partial` is workspace of frames*chunks*groups*2 floats. */

@@ -131,7 +131,9 @@ def test_golden_tiny_with_clstoken_readout(golden_dir, fp32):
         t, h, w, Cp = m.engine.stage(k)
         check_map(tag + k, nhwc_to_nchw(t, BT, h, w, Cp, C), z[k], tol_of("tiny.stage", fp32), tail=False)
     check_map(tag + "depth", d.cpu().numpy(), z["depth"], tol_of("tiny_cls.depth", fp32))
-    assert torch.equal(d, m.python_engine().forward(x, fp32=fp32))
+    m.engine.set_option("ln_fold", 0)                    # the Python launch sequence keeps the standalone LayerNorms
+    assert torch.equal(m.forward(x, fp32=fp32), m.python_engine().forward(x, fp32=fp32))
+    m.engine.set_option("ln_fold", 1)
     with pytest.raises(RuntimeError, match="Missing key"):          # the readout weights are part of the strict inventory
         m.load_state_dict(synthetic_state_dict(get_config("tiny"), seed=1), strict=True)
 
@@ -229,20 +231,67 @@ def test_oracle_metric_vitl_two_windows(fp32):
 def test_handle_and_python_orchestration_are_bit_identical(golden_dir):
     """vda_forward (csrc/host.hip: C++ weight packing + launch sequence) against engine.Engine (Python packing + the same
     launches through the per-kernel ABI): bit-identical outputs on the tiny and ViT-S fixtures, both precisions."""
+    # (the Python orchestration keeps the standalone LayerNorms: the handle runs with its "ln_fold" option off here)
     for name, fixture in (("tiny", "tiny_forward.npz"), ("vits", "vits_forward.npz")):
         z = np.load(os.path.join(golden_dir, fixture))
         m, _, _ = model_for(name, int(z["sd_seed"]))
         py = m.python_engine()
         x = torch.from_numpy(z["x"]).cuda()
-        for fp32 in (False, True):
-            a = m.forward(x, fp32=fp32).clone()
-            b = py.forward(x, fp32=fp32).clone()
-            assert torch.equal(a, b), f"{name} fp32={fp32}: {int((a != b).sum())} of {a.numel()} elements differ"
+        m.engine.set_option("ln_fold", 0)
+        try:
+            for fp32 in (False, True):
+                a = m.forward(x, fp32=fp32).clone()
+                b = py.forward(x, fp32=fp32).clone()
+                assert torch.equal(a, b), f"{name} fp32={fp32}: {int((a != b).sum())} of {a.numel()} elements differ"
+        finally:
+            m.engine.set_option("ln_fold", 1)
     # a square 518 frame too (stored pos-embed, 1370 tokens, the 256-row GEMM kernels)
     m, _, _ = model_for("vits", 11)
     py = m.python_engine()
     x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(74)).cuda()
-    assert torch.equal(m.forward(x, fp32=False), py.forward(x, fp32=False))
+    m.engine.set_option("ln_fold", 0)
+    try:
+        assert torch.equal(m.forward(x, fp32=False), py.forward(x, fp32=False))
+    finally:
+        m.engine.set_option("ln_fold", 1)
+
+
+def test_layernorm_fold_matches_the_standalone_layernorm(golden_dir):
+    """vda_set_option "ln_fold" (default on, fp16 path): LayerNorm folded into the encoder GEMMs either side of it (split fp16
+    residual stream, statistics from the residual epilogue, affine folded into qkv / fc1) against the standalone LayerNorm
+    launches: the two differ by operand rounding only (the stream is rounded to fp16 before instead of after the normalisation),
+    each is equally far from the fp32 oracle's golden output, and the option does not touch the fp32 path."""
+    z = np.load(os.path.join(golden_dir, "vits_forward.npz"))
+    m, _, _ = model_for("vits", int(z["sd_seed"]))
+    x = torch.from_numpy(z["x"]).cuda()
+    ref = z["depth"]
+    a = m.forward(x, fp32=False).clone()
+    f32 = m.forward(x, fp32=True).clone()
+    m.engine.set_option("ln_fold", 0)
+    try:
+        b = m.forward(x, fp32=False).clone()
+        assert torch.equal(f32, m.forward(x, fp32=True))
+    finally:
+        m.engine.set_option("ln_fold", 1)
+    assert torch.equal(a, m.forward(x, fp32=False))
+    e = rel_l1(a.cpu().numpy(), b.cpu().numpy())
+    ea, eb = rel_l1(a.cpu().numpy(), ref), rel_l1(b.cpu().numpy(), ref)
+    record("vits.ln_fold_vs_standalone", e)
+    record("vits.ln_fold.depth_vs_golden", ea)
+    record("vits.standalone_ln.depth_vs_golden", eb)
+    assert 0 < e < 1.4e-3 and ea < 1.4e-3 and eb < 1.4e-3
+    # a square 518 frame: 1370 tokens per frame, the 256-row kernels' row-layout epilogues (statistics from the epilogue itself)
+    m, _, _ = model_for("vits", 11)
+    x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(74)).cuda()
+    a = m.forward(x, fp32=False).clone()
+    m.engine.set_option("ln_fold", 0)
+    try:
+        b = m.forward(x, fp32=False).clone()
+    finally:
+        m.engine.set_option("ln_fold", 1)
+    e = rel_l1(a.cpu().numpy(), b.cpu().numpy())
+    record("vits.518.ln_fold_vs_standalone", e)
+    assert 0 < e < 1.4e-3
 
 
 def test_residual_in_layernorm_matches_the_epilogue_residual():
@@ -250,11 +299,15 @@ def test_residual_in_layernorm_matches_the_epilogue_residual():
     default - or fused into the next LayerNorm with the projection output stored as fp16) differ only by that fp16 rounding."""
     m, cfg, sd = model_for("vits", 0)
     x = torch.randn(1, 3, 3, 56, 70, generator=torch.Generator().manual_seed(102)).cuda()      # the vits_forward fixture's input
-    b = m.forward(x, fp32=False).clone()
-    m.engine.set_option("residual_in_ln", 1)
-    a = m.forward(x, fp32=False).clone()
-    m.engine.set_option("residual_in_ln", 0)
-    assert torch.equal(b, m.forward(x, fp32=False))
+    m.engine.set_option("ln_fold", 0)                     # both placements keep the standalone LayerNorm
+    try:
+        b = m.forward(x, fp32=False).clone()
+        m.engine.set_option("residual_in_ln", 1)
+        a = m.forward(x, fp32=False).clone()
+        m.engine.set_option("residual_in_ln", 0)
+        assert torch.equal(b, m.forward(x, fp32=False))
+    finally:
+        m.engine.set_option("ln_fold", 1)
     e = rel_l1(a.cpu().numpy(), b.cpu().numpy())
     record("vits.residual_in_ln_vs_epilogue", e)
     assert 0 < e < 1.4e-3           # measured 6.5e-4; each form is 6.4e-4 / 6.7e-4 from the fp32 oracle on this input (tools/res_ab.py)

@@ -193,6 +193,80 @@ def test_conv3x3(ops, gemm_variant, stride, relu_in, Cin, Cout, H, W_):
     close(out, ref, what="conv3x3")
 
 
+# ---------------------------------------------------------------- LayerNorm folded into the GEMMs either side of it
+def split_planes(x):
+    hi = x.to(F16)
+    return hi, (x - hi.float()).to(F16)
+
+
+@pytest.mark.parametrize("D,rows", [(1024, 37), (384, 50), (128, 9), (64, 130)])
+def test_split_stats_and_layernorm_split(ops, D, rows):
+    """fp32 rows -> (hi, lo) planes + (mean, rstd); LayerNorm of the split stream (with the cls-drop compaction)."""
+    x = rnd(rows, D, seed=140, scale=3.0) + 0.7
+    hi, lo = torch.empty(rows, D, dtype=F16, device="cuda"), torch.empty(rows, D, dtype=F16, device="cuda")
+    stat = torch.empty(rows, 2, device="cuda")
+    ops.split_stats(dev(x), hi, lo, stat, 1e-6, rows, D)
+    rh, rl = split_planes(x)
+    assert torch.equal(hi.cpu(), rh) and torch.equal(lo.cpu(), rl)
+    assert float(((hi.float() + lo.float()).cpu() - x).abs().max()) <= 2.0 ** -21 * float(x.abs().max())      # 22 significant bits
+    mean, var = x.double().mean(1), x.double().var(1, unbiased=False)
+    close(stat[:, 0], mean, rtol=1e-5, atol=1e-6, what="mean")
+    close(stat[:, 1], (var + 1e-6).rsqrt(), rtol=1e-5, atol=0, what="rstd")
+    w, b = rnd(D, seed=141) + 1.0, rnd(D, seed=142)
+    out = torch.empty(rows, D, dtype=F16, device="cuda")
+    ops.layernorm_split(hi, lo, out, dev(w), dev(b), 1e-6, rows, D)
+    close(out, F.layer_norm(x, (D,), w, b, 1e-6), what="layernorm of hi + lo")
+    if rows % 10 == 0:
+        G = 10
+        out = torch.empty(rows - rows // G, D, dtype=F16, device="cuda")
+        ops.layernorm_split(hi, lo, out, dev(w), dev(b), 1e-6, rows, D, group=G, skip=1)
+        close(out, F.layer_norm(x, (D,), w, b, 1e-6).reshape(-1, G, D)[:, 1:].reshape(-1, D), what="layernorm of hi + lo, cls dropped")
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 384, 384), (4100, 1024, 256), (2500, 384, 1536), (300, 64, 128)])
+def test_gemm_split_residual_and_stats(ops, gemm_variant, M, N, K):
+    """VDA_EPI_SCALE_RES_SPLIT in place over the two planes: x' = (hi + lo) + gamma * (A W^T + b), re-split; the per-64-column
+    partial statistics combine (vda_ln_stats_finalize) to the row's mean / rstd."""
+    from video_depth_anything_amd import _lib
+    A, W = rnd(M, K, seed=143).to(F16), rnd(N, K, seed=144, scale=K ** -0.5).to(F16)
+    b, gamma, x = rnd(N, seed=145), rnd(N, seed=146), rnd(M, N, seed=147, scale=3.0) + 0.3
+    hi0, lo0 = split_planes(x)
+    hi, lo = dev(hi0.clone()), dev(lo0.clone())
+    part = torch.full((M, N // 64, 2), float("nan"), device="cuda")
+    ops.gemm(dev(A), dev(W), hi, _lib.EPI_SCALE_RES_SPLIT, M=M, N=N, K=K, bias=dev(b), gamma=dev(gamma), res=hi, res2=lo, out2=lo, stats=part)
+    ref = (hi0.float() + lo0.float()) + gamma * (A.float() @ W.float().t() + b)
+    got = hi.float() + lo.float()
+    close(got, ref, rtol=1e-5, atol=2e-3, what="split residual stream")
+    assert bool(((hi.float() - got).abs() <= 2.0 ** -11 * got.abs() + 1e-7).all()), "the hi plane is the stream rounded to fp16 (lo at most half an ulp)"
+    stat = torch.empty(M, 2, device="cuda")
+    ops.ln_stats_finalize(part, stat, 1e-6, M, N // 64)
+    g = got.double().cpu()
+    close(stat[:, 0], g.mean(1), rtol=1e-5, atol=1e-5, what="mean from the epilogue's partials")
+    close(stat[:, 1], (g.var(1, unbiased=False) + 1e-6).rsqrt(), rtol=1e-4, atol=0, what="rstd from the epilogue's partials")
+
+
+@pytest.mark.parametrize("M,N,K", [(777, 1152, 384), (4100, 3072, 1024), (2500, 1536, 384), (300, 192, 128)])
+def test_gemm_layernorm_folded(ops, gemm_variant, M, N, K):
+    """qkv / fc1 with LayerNorm folded in: A = hi plane, W * diag(ln_w) (vda_fold_ln_weight), epilogue rstd * (acc - mean * c1) + c2
+    (then GELU) against LayerNorm(x) @ W^T + b evaluated in fp32 - including rows whose mean is far from zero."""
+    from video_depth_anything_amd import _lib
+    x = rnd(M, K, seed=150, scale=2.0) + rnd(M, 1, seed=151, scale=3.0)
+    Wt, b = rnd(N, K, seed=152, scale=K ** -0.5), rnd(N, seed=153)
+    lw, lb = rnd(K, seed=154) * 0.3 + 1.0, rnd(K, seed=155) * 0.3
+    Wf, c1, c2 = torch.empty(N, K, dtype=F16, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    ops.fold_ln_weight(dev(Wt), dev(b), dev(lw), dev(lb), Wf, c1, c2, N, K)
+    assert torch.equal(Wf.cpu(), (Wt * lw).to(F16))
+    close(c1, (Wt * lw).to(F16).float().sum(1), rtol=1e-5, atol=1e-5, what="c1")
+    close(c2, b + Wt @ lb, rtol=1e-5, atol=1e-5, what="c2")
+    hi, lo, stat = torch.empty(M, K, dtype=F16, device="cuda"), torch.empty(M, K, dtype=F16, device="cuda"), torch.empty(M, 2, device="cuda")
+    ops.split_stats(dev(x), hi, lo, stat, 1e-6, M, K)
+    ref = F.layer_norm(x, (K,), lw, lb, 1e-6) @ Wt.t() + b
+    for epi, fn in ((_lib.EPI_LN_BIAS_F16, lambda t: t), (_lib.EPI_LN_GELU_F16, F.gelu)):
+        out = torch.full((M, N), float("nan"), dtype=F16, device="cuda")
+        ops.gemm(hi, Wf, out, epi, M=M, N=N, K=K, bias=c2, gamma=c1, stats=stat)
+        close(out, fn(ref), rtol=3e-3, atol=6e-3, what=f"LayerNorm-folded GEMM epilogue {epi}")
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("D,rows", [(384, 50), (1024, 37), (128, 9), (64, 130)])
 def test_layernorm(ops, D, rows):

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libvda_hip.so")
 
 A_DENSE, A_CONV3X3 = 0, 1
 (EPI_BIAS_F16, EPI_BIAS_GELU_F16, EPI_BIAS_RELU_F16, EPI_SCALE_RES_F32, EPI_RES_F16, EPI_GEGLU_F16,
- EPI_PATCH_F32, EPI_CONVT_F16, EPI_BIAS_F32, EPI_SCALE_RES_F32_H) = range(10)
+ EPI_PATCH_F32, EPI_CONVT_F16, EPI_BIAS_F32, EPI_SCALE_RES_F32_H, EPI_SCALE_RES_SPLIT, EPI_LN_BIAS_F16, EPI_LN_GELU_F16) = range(13)
 
 
 class GemmArgs(C.Structure):
@@ -22,6 +22,7 @@ class GemmArgs(C.Structure):
         ("cB", C.c_int32), ("cH", C.c_int32), ("cW", C.c_int32), ("cCin", C.c_int32),
         ("cHo", C.c_int32), ("cWo", C.c_int32), ("cStride", C.c_int32),
         ("P", C.c_int32), ("tK", C.c_int32), ("tH", C.c_int32), ("tW", C.c_int32), ("tCout", C.c_int32),
+        ("out2", C.c_void_p), ("stats", C.c_void_p),
     ]
 
 
@@ -45,6 +46,10 @@ SIGNATURES = {
     "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_layernorm_residual_f32_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_layernorm_f32_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "vda_split_stats_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "vda_ln_stats_finalize": (_i, [_vp, _vp, _f, _i, _i, _vp]),
+    "vda_layernorm_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
+    "vda_fold_ln_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_groupnorm_nhwc_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),

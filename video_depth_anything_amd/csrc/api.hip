@@ -12,4 +12,4 @@ extern "C" void vda_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vda_last_error(void) { return g_err; }
-extern "C" int vda_abi_version(void) { return 3; }
+extern "C" int vda_abi_version(void) { return 4; }

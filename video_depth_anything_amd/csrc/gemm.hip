@@ -182,6 +182,28 @@ int launch(const vda_gemm_args& a, hipStream_t s) {
     return 0;
 }
 
+// Partial row statistics of the split stream for the kernels whose epilogue is not row-layout (small problems only):
+// part[m, j, :] = (sum, centred sum of squares) of hi + lo over columns 64j..64j+63, one lane per (row, 64-column block).
+__global__ void __launch_bounds__(256) split_partials_kernel(const h16* __restrict__ hi, const h16* __restrict__ lo, float* __restrict__ part,
+                                                             int M, int N, int ldc) {
+    const int np = N >> 6;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * np) return;
+    const int m = (int)(i / np), j = (int)(i - (long long)m * np);
+    const h16* a = hi + (size_t)m * ldc + j * 64;
+    const h16* b = lo + (size_t)m * ldc + j * 64;
+    float sum = 0.f;
+    for (int e = 0; e < 64; ++e) sum += (float)a[e] + (float)b[e];
+    const float mean = sum * (1.f / 64.f);
+    float sq = 0.f;
+    for (int e = 0; e < 64; ++e) {
+        const float d = ((float)a[e] + (float)b[e]) - mean;
+        sq = fmaf(d, d, sq);
+    }
+    part[2 * i] = sum;
+    part[2 * i + 1] = sq;
+}
+
 }  // namespace
 
 // gemm256_*.hip: return -1 when the (A mode, epilogue) pair is not instantiated for the large tile
@@ -215,6 +237,23 @@ static int vda_gemm256_launch(const vda_gemm_args& a, int bn, hipStream_t s) {
     return bn == 256 ? vda_gemm256_conv_bn256(a, s) : vda_gemm256_conv_bn128(a, s);
 }
 
+// the 128-row kernel (any size, any epilogue)
+static int launch_small(const vda_gemm_args& a, hipStream_t s) {
+    const bool narrow = a.N <= 64;
+    if (a.a_mode == VDA_A_DENSE) {
+        const int rc = narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
+        if (rc == 0 && a.epilogue == VDA_EPI_SCALE_RES_SPLIT && a.stats != nullptr) {
+            // this kernel's epilogue does not own whole row segments: the partial statistics come from a pass over the planes
+            const long long items = (long long)a.M * (a.N >> 6);
+            hipLaunchKernelGGL(split_partials_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const h16*)a.out, (const h16*)a.out2, a.stats, a.M,
+                               a.N, a.ldc);
+            VDA_LAUNCH_CHECK();
+        }
+        return rc;
+    }
+    return narrow ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
+}
+
 static int g_gemm_variant = -1;   // tuning / A-B hook, see the dispatch in vda_gemm_f16
 
 static thread_local const char* g_last_kernel = "";
@@ -235,7 +274,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     VDA_REQUIRE(a.N % 4 == 0 && a.ldc % 4 == 0, "vda_gemm_f16: N=%d and ldc=%d must be multiples of 4", a.N, a.ldc);
     VDA_REQUIRE(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0 && ((uintptr_t)a.out & 15) == 0,
                 "vda_gemm_f16: operands must be 16-byte aligned");
-    VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_SCALE_RES_F32_H, "vda_gemm_f16: bad epilogue %d", a.epilogue);
+    VDA_REQUIRE(a.epilogue >= 0 && a.epilogue <= VDA_EPI_LN_GELU_F16, "vda_gemm_f16: bad epilogue %d", a.epilogue);
     if (a.a_mode == VDA_A_DENSE) {
         VDA_REQUIRE(a.relu_in == 0, "vda_gemm_f16: relu_in is only built for the conv A operand");
         VDA_REQUIRE((a.lda >= a.K || a.lda == 0) && a.lda % 8 == 0, "vda_gemm_f16: lda=%d must be >= K (or 0 = broadcast row) and a multiple of 8", a.lda);
@@ -258,6 +297,18 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             break;
         case VDA_EPI_GEGLU_F16:
             VDA_REQUIRE(a.N % 32 == 0, "vda_gemm_f16: GEGLU needs N%%32==0");
+            break;
+        case VDA_EPI_SCALE_RES_SPLIT:
+            VDA_REQUIRE(a.res != nullptr && a.res2 != nullptr && a.out2 != nullptr, "vda_gemm_f16: the split-residual epilogue needs res, res2 (hi / lo planes) and out2");
+            VDA_REQUIRE(a.N % 64 == 0 && a.ldc % 8 == 0 && a.a_mode == VDA_A_DENSE, "vda_gemm_f16: the split-residual epilogue needs a dense A operand, N%%64==0 and ldc%%8==0");
+            VDA_REQUIRE(((uintptr_t)a.res & 15) == 0 && ((uintptr_t)a.res2 & 15) == 0 && ((uintptr_t)a.out2 & 15) == 0 && ((uintptr_t)a.stats & 7) == 0,
+                        "vda_gemm_f16: split-residual planes must be 16-byte aligned");
+            break;
+        case VDA_EPI_LN_BIAS_F16:
+        case VDA_EPI_LN_GELU_F16:
+            VDA_REQUIRE(a.stats != nullptr && a.gamma != nullptr && a.bias != nullptr && a.a_mode == VDA_A_DENSE,
+                        "vda_gemm_f16: a LayerNorm-folded epilogue needs a dense A operand, stats (mean, rstd rows), gamma (= c1) and bias (= c2)");
+            VDA_REQUIRE(((uintptr_t)a.stats & 7) == 0, "vda_gemm_f16: stats must be 8-byte aligned");
             break;
         case VDA_EPI_PATCH_F32:
             VDA_REQUIRE(a.pos != nullptr && a.P > 0 && a.M % a.P == 0, "vda_gemm_f16: patch epilogue needs pos and M%%P==0");
@@ -282,11 +333,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     }
     const bool fits32 = (a.a_mode == VDA_A_DENSE ? (long long)a.M * a.lda : 0ll) + a.K < (1ll << 31) && (long long)a.N * a.K < (1ll << 31);
     VDA_REQUIRE(fits32 || g_gemm_variant == 0 || g_gemm_variant < 0, "vda_gemm_f16: operand too large for the 256-row kernel's 32-bit offsets");
-    if (!fits32) {
-        const bool narrow0 = a.N <= 64;
-        if (a.a_mode == VDA_A_DENSE) return narrow0 ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
-        return narrow0 ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
-    }
+    if (!fits32) return launch_small(a, s);
     // variants: -1 auto; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 on 32x32x16 MFMA; 3 / 4 = the same on 16x16x32 MFMA;
     // 5 = 256x256 8-phase two-group schedule (16x16x32 MFMA)
     int big = 0, small_mfma = 1;
@@ -336,7 +383,5 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     }
     g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
                                             : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
-    const bool narrow = a.N <= 64;
-    if (a.a_mode == VDA_A_DENSE) return narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
-    return narrow ? launch<128, 64, VDA_A_CONV3X3>(a, s) : launch<128, 128, VDA_A_CONV3X3>(a, s);
+    return launch_small(a, s);
 }

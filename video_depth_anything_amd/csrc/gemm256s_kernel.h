@@ -362,6 +362,9 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
         case VDA_EPI_CONVT_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_CONVT_F16>(a, s);
         case VDA_EPI_BIAS_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F32>(a, s);
         case VDA_EPI_SCALE_RES_F32_H: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32_H>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16>(a, s);
         default: break;
     }
     return -1;

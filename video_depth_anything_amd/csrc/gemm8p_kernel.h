@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = bnn * BN + wn * WTN + j * 16 + (lane >> 4) * 4;
-            nbias[j] = (p.bias != nullptr && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (LayerNorm-folded epilogues add their constant AFTER the row scaling: the accumulators start at zero)
+            nbias[j] = (!vda_gemm::is_ln_epi<EPI> && p.bias != nullptr && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
 
@@ -480,7 +481,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
                 // Epilogues with row-dependent loads (residual, pos-embed) prefetch after their LAST block instead: with an LDS-DMA
                 // in flight hipcc waits vmcnt(0) - every store included - at each of those loads (dbg bit 2 switches this off)
-                constexpr bool ROW_AUX = EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H || EPI == VDA_EPI_RES_F16 || EPI == VDA_EPI_PATCH_F32;
+                constexpr bool ROW_AUX = EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H || EPI == VDA_EPI_RES_F16 || EPI == VDA_EPI_PATCH_F32 ||
+                                         EPI == VDA_EPI_SCALE_RES_SPLIT || vda_gemm::is_ln_epi<EPI>;
                 const int pf_block = (ROW_AUX && !(dbg & 4)) ? MI / 2 - 1 : 0;
                 if (i == pf_block && next < ntiles && !(dbg & 1)) {
                     load_bias(next);
@@ -530,6 +532,9 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
         case VDA_EPI_CONVT_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_CONVT_F16>(a, s);
         case VDA_EPI_BIAS_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F32>(a, s);
         case VDA_EPI_SCALE_RES_F32_H: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32_H>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16>(a, s);
         default: break;
     }
     return -1;

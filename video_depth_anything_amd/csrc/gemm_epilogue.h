@@ -18,10 +18,61 @@ __device__ __forceinline__ h16 to_h16(float v) {
 }
 
 template <int EPI>
+inline constexpr bool is_ln_epi = (EPI == VDA_EPI_LN_BIAS_F16 || EPI == VDA_EPI_LN_GELU_F16);
+
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): the split fp32 residual stream (VDA_EPI_SCALE_RES_SPLIT)
+__device__ __forceinline__ void split_h16(float x, h16& hi, h16& lo) {
+    hi = to_h16(x);
+    lo = to_h16(x - (float)hi);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float epi_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 8 lanes (aligned group) that own one row's 64 columns in the row-layout epilogue
+__device__ __forceinline__ float sum8(float v) {
+    v += epi_dpp<0xB1>(v);                  // quad_perm [1,0,3,2]
+    v += epi_dpp<0x4E>(v);                  // quad_perm [2,3,0,1]
+    v += epi_dpp<0x141>(v);                 // row_half_mirror
+    return v;
+}
+
+template <int EPI>
 __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, f32x4 v, f32x4 g) {
     // v: accumulators for columns n..n+3 of row m (g: gate accumulators, GEGLU only).
     if (m >= p.M || n >= p.N) return;
+    if constexpr (is_ln_epi<EPI>) {
+        const float mu = p.stats[2 * (size_t)m], rstd = p.stats[2 * (size_t)m + 1];
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.gamma + n), c2 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = fmaf(rstd, fmaf(-mu, c1[i], v[i]), c2[i]);
+            if constexpr (EPI == VDA_EPI_LN_GELU_F16) v[i] = gelu_erf(v[i]);
+        }
+        h16x4 o = {to_h16(v[0]), to_h16(v[1]), to_h16(v[2]), to_h16(v[3])};
+        *reinterpret_cast<h16x4*>((h16*)p.out + (size_t)m * p.ldc + n) = o;
+        return;
+    }
     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
+        // (the partial row statistics are written by a separate pass for this layout: see vda_gemm_f16)
+        const size_t off = (size_t)m * p.ldc + n;
+        const h16x4 rh = *reinterpret_cast<const h16x4*>((const h16*)p.res + off), rl = *reinterpret_cast<const h16x4*>((const h16*)p.res2 + off);
+        h16x4 oh, ol;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g = p.gamma ? p.gamma[n + i] : 1.f;
+            const float x = fmaf(g, v[i], (float)rh[i] + (float)rl[i]);
+            h16 a, b;
+            split_h16(x, a, b);
+            oh[i] = a;
+            ol[i] = b;
+        }
+        *reinterpret_cast<h16x4*>((h16*)p.out + off) = oh;
+        *reinterpret_cast<h16x4*>((h16*)p.out2 + off) = ol;
+        return;
+    }
     if constexpr (EPI == VDA_EPI_BIAS_F16 || EPI == VDA_EPI_BIAS_GELU_F16 || EPI == VDA_EPI_BIAS_RELU_F16) {
         if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
 #pragma unroll
@@ -131,7 +182,7 @@ __device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, Co
         c.gbias[i] = 0.f;
     }
     if (!ok) return;
-    if (BIAS && p.bias) {
+    if ((BIAS || is_ln_epi<EPI>) && p.bias) {
 #pragma unroll
         for (int i = 0; i < NC; i += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n + i);
@@ -149,7 +200,7 @@ __device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, Co
             }
         }
     }
-    if constexpr (EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H) {
+    if constexpr (EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H || EPI == VDA_EPI_SCALE_RES_SPLIT || is_ln_epi<EPI>) {
         if (p.gamma) {
 #pragma unroll
             for (int i = 0; i < NC; i += 4) {
@@ -167,6 +218,7 @@ __device__ __forceinline__ void load_col_const(const vda_gemm_args& p, int n, Co
 struct RowAux {
     f32x4 f0, f1;
     h16x8 h0, h1;
+    float s0, s1;        // LayerNorm-folded epilogues: the row's (mean, rstd)
 };
 
 // GUARD = false: the caller has established that every row / column of the wave's tile is inside the matrix. The bounds
@@ -188,6 +240,14 @@ __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int 
     } else if constexpr (EPI == VDA_EPI_PATCH_F32) {
         const int q = m % p.P;
         x.f0 = *reinterpret_cast<const f32x4*>(p.pos + (size_t)(1 + q) * p.N + n);
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
+        const size_t off = (size_t)m * p.ldc + n;
+        x.h0 = *reinterpret_cast<const h16x8*>((const h16*)p.res + off);
+        x.h1 = *reinterpret_cast<const h16x8*>((const h16*)p.res2 + off);
+    } else if constexpr (is_ln_epi<EPI>) {
+        const float2 st = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)m);
+        x.s0 = st.x;
+        x.s1 = st.y;
     }
 }
 
@@ -195,11 +255,47 @@ template <int EPI, bool GUARD = true, bool BIAS = true>
 __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n, float (&v)[8], float (&g)[8],
                                             const ColConst<8>& c, const RowAux& x) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
-    if constexpr (BIAS) {
+    if constexpr (BIAS && !is_ln_epi<EPI>) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += c.bias[i];
     }
-    if constexpr (EPI == VDA_EPI_BIAS_F16) {
+    if constexpr (is_ln_epi<EPI>) {
+        // LayerNorm applied AFTER the GEMM: acc = sum_k hi[m,k] * (W[n,k] * ln_w[k]); c.gamma = c1 (row sums of the folded W), c.bias = c2
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = fmaf(x.s1, fmaf(-x.s0, c.gamma[i], v[i]), c.bias[i]);
+            if constexpr (EPI == VDA_EPI_LN_GELU_F16) v[i] = gelu_erf(v[i]);
+        }
+        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+    } else if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
+        // the row's 64 columns of this wave tile sit in 8 consecutive lanes (all inside the matrix together: N % 64 == 0)
+        h16x8 oh, ol;
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = fmaf(c.gamma[i], v[i], (float)x.h0[i] + (float)x.h1[i]);    // hi + lo is exact in fp32
+            h16 a, b;
+            split_h16(v[i], a, b);
+            oh[i] = a;
+            ol[i] = b;
+        }
+        const size_t off = (size_t)m * p.ldc + n;
+        *reinterpret_cast<h16x8*>((h16*)p.out + off) = oh;
+        *reinterpret_cast<h16x8*>((h16*)p.out2 + off) = ol;
+        if (p.stats) {
+            sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            sum = sum8(sum);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = v[i] - mean;
+                sq = fmaf(d, d, sq);
+            }
+            sq = sum8(sq);
+            if ((n & 63) == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2) = float2{sum, sq};
+        }
+    } else if constexpr (EPI == VDA_EPI_BIAS_F16) {
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
 #pragma unroll
@@ -275,6 +371,9 @@ __device__ __forceinline__ void dispatch_epilogue(int epilogue, F&& f) {
         case VDA_EPI_CONVT_F16: f(std::integral_constant<int, VDA_EPI_CONVT_F16>{}); break;
         case VDA_EPI_BIAS_F32: f(std::integral_constant<int, VDA_EPI_BIAS_F32>{}); break;
         case VDA_EPI_SCALE_RES_F32_H: f(std::integral_constant<int, VDA_EPI_SCALE_RES_F32_H>{}); break;
+        case VDA_EPI_SCALE_RES_SPLIT: f(std::integral_constant<int, VDA_EPI_SCALE_RES_SPLIT>{}); break;
+        case VDA_EPI_LN_BIAS_F16: f(std::integral_constant<int, VDA_EPI_LN_BIAS_F16>{}); break;
+        case VDA_EPI_LN_GELU_F16: f(std::integral_constant<int, VDA_EPI_LN_GELU_F16>{}); break;
         default: break;
     }
 }

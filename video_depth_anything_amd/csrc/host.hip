@@ -14,6 +14,7 @@
 #include "vda_common.h"
 #include <string.h>
 #include <exception>
+#include <type_traits>
 #include <array>
 #include <map>
 #include <string>
@@ -95,6 +96,10 @@ inline unsigned grid_for(size_t items) {
     return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
 }
 
+#ifndef VDA_LN_FOLD_DEFAULT
+#define VDA_LN_FOLD_DEFAULT 1
+#endif
+
 struct Raw {
     float* d = nullptr;
     std::vector<int64_t> dims;
@@ -144,6 +149,7 @@ struct vda_model {
     std::array<int, 5> last_key = {0, 0, 0, 0, -1};
     Profile prof;
     int residual_in_ln = 0;                   // vda_set_option("residual_in_ln"): see Run::forward (off: measured slower end to end)
+    int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
 };
 
 namespace {
@@ -323,6 +329,23 @@ int pack_all(vda_model* h, int prec) {
         VDA_TRY(lin(k + "attn.proj.weight", b + "attn.proj.weight", D, D, D, D));
         VDA_TRY(lin(k + "mlp.fc1.weight", b + "mlp.fc1.weight", 4 * D, D, 4 * D, D));
         VDA_TRY(lin(k + "mlp.fc2.weight", b + "mlp.fc2.weight", D, 4 * D, D, 4 * D));
+        if constexpr (std::is_same<T, h16>::value) {
+            // LayerNorm folded into the Linear behind it (vda.h, VDA_EPI_LN_*): W * diag(ln_w) in fp16, c1 = its row sums, c2 = b + W.ln_b
+            const char* pairs[2][3] = {{"attn.qkv", "norm1", nullptr}, {"mlp.fc1", "norm2", nullptr}};
+            const int outs[2] = {3 * D, 4 * D};
+            for (int j = 0; j < 2; ++j) {
+                const std::string lk = pairs[j][0], nk = pairs[j][1];
+                T* d = nullptr;
+                VDA_TRY(mat(k + lk + ".weight.ln", (size_t)outs[j] * D, &d));
+                void *c1 = nullptr, *c2 = nullptr;
+                VDA_TRY(dev_alloc(h, (size_t)outs[j] * sizeof(float), &c1));
+                VDA_TRY(dev_alloc(h, (size_t)outs[j] * sizeof(float), &c2));
+                h->vec[k + lk + ".c1"] = (float*)c1;
+                h->vec[k + lk + ".c2"] = (float*)c2;
+                VDA_TRY(vda_fold_ln_weight(raw(b + lk + ".weight"), raw(b + lk + ".bias"), raw(b + nk + ".weight"), raw(b + nk + ".bias"), d, (float*)c1,
+                                           (float*)c2, outs[j], D, s));
+            }
+        }
     }
     VDA_TRY(vecp("norm.w", p + "norm.weight", D, D));
     VDA_TRY(vecp("norm.b", p + "norm.bias", D, D));
@@ -606,6 +629,36 @@ struct Run {
         // projection GEMMs get 15 % faster (1040 vs 902 TFLOP/s) but the LayerNorm doubles its bytes (12 B per element at
         // 5.05 TB/s): +1.1 ms per clip net (57.9 vs 56.8 ms). Kept as an A/B option, off.
         const bool defer = prec == VDA_PREC_F16 && h->residual_in_ln != 0;
+        // Option ln_fold (fp16 path, default): no LayerNorm pass at all inside the encoder. The residual stream lives as two fp16
+        // planes (x = hi + lo; VDA_EPI_SCALE_RES_SPLIT reads and writes both, 8 bytes per element like the fp32 stream, and leaves
+        // per-row partial statistics); qkv / fc1 take the hi plane as their A operand with LayerNorm's affine folded into their
+        // weights and apply rstd * (acc - mean * c1) + c2 in their epilogue (VDA_EPI_LN_*). Only the four taps still run a LayerNorm.
+        const bool fold = prec == VDA_PREC_F16 && h->ln_fold != 0 && !defer && D % 64 == 0;
+        void* thi = fold ? buf("tok_hi", (size_t)rows * D, 2) : nullptr;
+        void* tlo = fold ? buf("tok_lo", (size_t)rows * D, 2) : nullptr;
+        float* lnpart = fold ? f32("ln_part", (size_t)rows * (D / 64) * 2) : nullptr;
+        float* lnstat = fold ? f32("ln_stat", (size_t)rows * 2) : nullptr;
+        if (fold && !dry) VDA_TRY(vda_split_stats_f32(tok, thi, tlo, lnstat, ENC_LN_EPS, rows, D, s));
+        auto ln_gemm = [&](const std::string& wk, void* out, int epi, int N) -> int {         // LayerNorm(x) @ W^T + b on the hi plane
+            vda_gemm_args a = {};
+            a.A = thi, a.W = W(wk + ".weight.ln"), a.out = out, a.bias = V(wk + ".c2"), a.gamma = V(wk + ".c1"), a.stats = lnstat;
+            a.M = rows, a.N = N, a.K = D, a.a_mode = VDA_A_DENSE, a.epilogue = epi;
+            return gemm(a);
+        };
+        auto res_gemm = [&](const void* A, const std::string& wk, const std::string& gk, int K, bool stats_next) -> int {   // x += gamma * (A @ W^T + b)
+            vda_gemm_args a = {};
+            a.A = A, a.W = W(wk + ".weight"), a.out = thi, a.out2 = tlo, a.res = thi, a.res2 = tlo, a.bias = V(wk + ".bias"), a.gamma = V(gk);
+            a.stats = stats_next ? lnpart : nullptr;
+            a.M = rows, a.N = D, a.K = K, a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_SCALE_RES_SPLIT;
+            VDA_TRY(gemm(a));
+            if (stats_next && !dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, s));
+            return 0;
+        };
+        auto tap_ln = [&](void* out, int group, int skip) -> int {
+            if (dry) return 0;
+            return fold ? vda_layernorm_split_f16(thi, tlo, out, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, group, skip, s)
+                        : vda_layernorm_f32_f16(tok, out, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D, group, skip, nullptr, 0, 0, s);
+        };
         void* yb = defer ? act("ybuf", (size_t)rows * D) : nullptr;
         auto ln_res = [&](const float* gamma, void* out, const float* w, const float* b, int group, int skip) -> int {
             if (dry) return 0;
@@ -614,23 +667,33 @@ struct Run {
         bool xn_ready = false;                 // norm1 of block i already ran (fused with block i-1's fc2 residual)
         for (int i = 0; i < c.depth; ++i) {
             const std::string k = "b" + std::to_string(i) + ".";
-            if (!xn_ready) VDA_TRY(layernorm(tok, xn, V(k + "norm1.weight"), V(k + "norm1.bias"), ENC_LN_EPS, rows, D));
-            xn_ready = false;
-            VDA_TRY(dense(xn, W(k + "attn.qkv.weight"), qkv, VDA_EPI_BIAS_F16, rows, 3 * D, D, V(k + "attn.qkv.bias")));
+            if (fold) {
+                VDA_TRY(ln_gemm(k + "attn.qkv", qkv, VDA_EPI_LN_BIAS_F16, 3 * D));
+            } else {
+                if (!xn_ready) VDA_TRY(layernorm(tok, xn, V(k + "norm1.weight"), V(k + "norm1.bias"), ENC_LN_EPS, rows, D));
+                xn_ready = false;
+                VDA_TRY(dense(xn, W(k + "attn.qkv.weight"), qkv, VDA_EPI_BIAS_F16, rows, 3 * D, D, V(k + "attn.qkv.bias")));
+            }
             if (!dry) VDA_TRY(prec == VDA_PREC_F32 ? vda_attention_f32((const float*)qkv, (float*)ao, BT, Nt, NH, s) : vda_attention_f16(qkv, ao, BT, Nt, NH, s));
-            if (defer) {
+            if (fold) {
+                VDA_TRY(res_gemm(ao, k + "attn.proj", k + "ls1.gamma", D, true));
+            } else if (defer) {
                 VDA_TRY(dense(ao, W(k + "attn.proj.weight"), yb, VDA_EPI_BIAS_F16, rows, D, D, V(k + "attn.proj.bias")));
                 VDA_TRY(ln_res(V(k + "ls1.gamma"), xn, V(k + "norm2.weight"), V(k + "norm2.bias"), 0, 0));
             } else {
                 VDA_TRY(dense(ao, W(k + "attn.proj.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, D, V(k + "attn.proj.bias"), tok, V(k + "ls1.gamma")));
                 VDA_TRY(layernorm(tok, xn, V(k + "norm2.weight"), V(k + "norm2.bias"), ENC_LN_EPS, rows, D));
             }
-            VDA_TRY(dense(xn, W(k + "mlp.fc1.weight"), hid, VDA_EPI_BIAS_GELU_F16, rows, 4 * D, D, V(k + "mlp.fc1.bias")));
+            if (fold) VDA_TRY(ln_gemm(k + "mlp.fc1", hid, VDA_EPI_LN_GELU_F16, 4 * D));
+            else VDA_TRY(dense(xn, W(k + "mlp.fc1.weight"), hid, VDA_EPI_BIAS_GELU_F16, rows, 4 * D, D, V(k + "mlp.fc1.bias")));
             bool is_tap = false;
             for (int t = 0; t < 4; ++t) is_tap = is_tap || c.taps[t] == i;
             const bool last = i + 1 == c.depth;
             void* tp = (is_tap && ntap < 4) ? act("tap" + std::to_string(ntap), (size_t)BT * P * D) : nullptr;
-            if (defer) {
+            if (fold) {
+                VDA_TRY(res_gemm(hid, k + "mlp.fc2", k + "ls2.gamma", 4 * D, !last));
+                if (tp != nullptr) VDA_TRY(tap_ln(tp, Nt, 1));                                             // final norm, cls dropped
+            } else if (defer) {
                 VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), yb, VDA_EPI_BIAS_F16, rows, D, 4 * D, V(k + "mlp.fc2.bias")));
                 if (last && tp != nullptr) {
                     VDA_TRY(ln_res(V(k + "ls2.gamma"), tp, V("norm.w"), V("norm.b"), Nt, 1));            // residual + final norm, cls dropped
@@ -649,7 +712,7 @@ struct Run {
                     // dpt_temporal.py:56-59: the tap becomes GELU(Linear([patch token, cls])); the final norm above dropped the cls
                     // row, so norm the whole token matrix again (cls kept) and gather [patch | cls] rows for one K = 2D GEMM
                     void* full = act("rd_full", (size_t)rows * D);
-                    VDA_TRY(layernorm(tok, full, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D));
+                    VDA_TRY(fold ? tap_ln(full, 0, 0) : layernorm(tok, full, V("norm.w"), V("norm.b"), ENC_LN_EPS, rows, D));
                     void* cat = act("rd_cat", (size_t)BT * P * 2 * D);
                     if (!dry)
                         VDA_TRY(prec == VDA_PREC_F32 ? vda_readout_concat_f32((const float*)full, (float*)cat, BT, P, D, s)
@@ -948,12 +1011,17 @@ static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_
     return 0;
 }
 
-// Tuning / A-B switches of the launch sequence. "residual_in_ln" (default 0): see Run::forward.
+// Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1): see Run::forward.
 extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     VDA_REQUIRE(h && name, "vda_set_option: null argument");
     if (strcmp(name, "residual_in_ln") == 0) {
         h->residual_in_ln = value;
         h->layouts.clear();                  // the workspace layout depends on it
+        return 0;
+    }
+    if (strcmp(name, "ln_fold") == 0) {
+        h->ln_fold = value;
+        h->layouts.clear();
         return 0;
     }
     vda_set_error("vda_set_option: unknown option %s", name);

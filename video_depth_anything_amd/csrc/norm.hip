@@ -221,6 +221,137 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const T* __restric
     }
 }
 
+// ---------------------------------------------------------------- LayerNorm folded into the neighbouring GEMMs
+// The fp32 residual stream of the encoder is kept as two fp16 planes, x = hi + lo (vda.h, VDA_EPI_SCALE_RES_SPLIT).
+//   MODE 0 (vda_split_stats_f32): fp32 rows -> hi, lo planes + stat[row] = (mean, rstd): the entry into the split stream.
+//   MODE 1 (vda_layernorm_split_f16): LayerNorm(hi + lo) * w + b -> fp16, group / skip as layernorm_kernel (the taps).
+// Same row-in-registers, two-pass fp32 statistics as layernorm_kernel.
+template <int LPR, int NCH, int MODE>
+__global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__ xin, const h16* __restrict__ hin, const h16* __restrict__ lin,
+                                                       h16* __restrict__ o0, h16* __restrict__ o1, float* __restrict__ stat,
+                                                       const float* __restrict__ w, const float* __restrict__ b, float eps, int rows, int D,
+                                                       int group, int skip) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsel = lane / LPR;
+    const int row = (blockIdx.x * 4 + wave) * RPW + rsel;
+    const bool row_ok = row < rows;
+    const int nchunk = D >> 3;
+    const size_t base = (size_t)(row_ok ? row : 0) * D;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = sub + c * LPR;
+        const bool ok = row_ok && ch < nchunk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        if (ok) {
+            if constexpr (MODE == 0) {
+                load8(xin + base + ch * 8, v[c]);
+            } else {
+                const h16x8 a = *reinterpret_cast<const h16x8*>(hin + base + ch * 8), l = *reinterpret_cast<const h16x8*>(lin + base + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[c][e] = (float)a[e] + (float)l[e];
+            }
+        }
+        sum += ((v[c][0] + v[c][1]) + (v[c][2] + v[c][3])) + ((v[c][4] + v[c][5]) + (v[c][6] + v[c][7]));
+    }
+    const float mean = segment_sum<LPR>(sum, lane) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const bool ok = sub + c * LPR < nchunk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = ok ? v[c][e] - mean : 0.f;
+            sq += d * d;
+        }
+    }
+    const float rstd = rsqrtf(segment_sum<LPR>(sq, lane) / (float)D + eps);
+    if (!row_ok) return;
+    if constexpr (MODE == 0) {
+        if (sub == 0) *reinterpret_cast<float2*>(stat + 2 * (size_t)row) = float2{mean, rstd};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = sub + c * LPR;
+            if (ch < nchunk) {
+                h16x8 a, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    a[e] = (h16)v[c][e];
+                    l[e] = (h16)(v[c][e] - (float)a[e]);
+                }
+                *reinterpret_cast<h16x8*>(o0 + base + ch * 8) = a;
+                *reinterpret_cast<h16x8*>(o1 + base + ch * 8) = l;
+            }
+        }
+    } else {
+        int orow = row;
+        if (group > 0) {
+            const int g = row / group, i = row - g * group;
+            if (i < skip) return;
+            orow = g * (group - skip) + (i - skip);
+        }
+        h16* dst = o0 + (size_t)orow * D;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = sub + c * LPR;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + ch * 8 + h * 4);
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(b + ch * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[h * 4 + e] = (v[c][h * 4 + e] - mean) * rstd * ww[e] + bb[e];
+                }
+                store8(dst + ch * 8, o);
+            }
+        }
+    }
+}
+
+// partial[r, np, 2] = (sum, centred sum of squares) per 64 columns -> stat[r] = (mean, rstd); pairwise update in column order
+// (Chan, Golub, LeVeque): no E[x^2] - mean^2 cancellation, fixed order.
+__global__ void __launch_bounds__(256) ln_stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, float eps, int rows, int np) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float2* p = reinterpret_cast<const float2*>(partial) + (size_t)r * np;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j = 0; j < np; ++j) {
+        const float2 q = p[j];
+        const float mb = q.x * (1.f / 64.f), delta = mb - mean, nn = n + 64.f;
+        mean += delta * (64.f / nn);
+        m2 += q.y + delta * delta * (n * 64.f / nn);
+        n = nn;
+    }
+    *reinterpret_cast<float2*>(stat + 2 * (size_t)r) = float2{mean, rsqrtf(m2 / n + eps)};
+}
+
+// Pack-time fold of LayerNorm's affine into the following Linear: one wave per output row.
+__global__ void __launch_bounds__(64) fold_ln_weight_kernel(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, h16* __restrict__ Wf, float* __restrict__ c1,
+                                                            float* __restrict__ c2, int N, int K) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = W[(size_t)n * K + k];
+        float t = wv * ln_w[k];
+        asm volatile("" : "+v"(t));             // round to fp32, then to fp16 (no fused multiply-convert): the documented definition
+        const h16 f = (h16)t;
+        Wf[(size_t)n * K + k] = f;
+        s1 += (float)f;
+        s2 = fmaf(wv, ln_b[k], s2);
+    }
+    s1 = segment_sum<64>(s1, lane);
+    s2 = segment_sum<64>(s2, lane);
+    if (lane == 0) {
+        c1[n] = s1;
+        c2[n] = s2 + (bias ? bias[n] : 0.f);
+    }
+}
+
 }  // namespace
 
 template <typename OT, bool RES = false>
@@ -266,6 +397,58 @@ extern "C" int vda_layernorm_f32_f32(const float* in, float* out, const float* w
                                      int group, int skip, const float* pe, int pe_rows_per_step, int pe_steps,
                                      vda_stream_t stream) {
     return layernorm_launch<float>(const_cast<float*>(in), out, w, b, eps, rows, D, group, skip, pe, pe_rows_per_step, pe_steps, stream);
+}
+
+template <int MODE>
+static int ln_split_launch(const float* xin, const h16* hin, const h16* lin, h16* o0, h16* o1, float* stat, const float* w, const float* b, float eps,
+                           int rows, int D, int group, int skip, vda_stream_t stream) {
+    VDA_REQUIRE(rows > 0 && D > 0 && D % 8 == 0 && D <= 2048, "vda_layernorm_split / vda_split_stats: D=%d must be a multiple of 8 and <= 2048", D);
+    VDA_REQUIRE(group == 0 || (group > 0 && skip >= 0 && skip < group && rows % group == 0), "vda_layernorm_split: bad group/skip");
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = D / 8;
+#define VDA_LNS_LAUNCH(LPR, NCH)                                                                                                          \
+    hipLaunchKernelGGL((ln_split_kernel<LPR, NCH, MODE>), dim3((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR))), dim3(256), 0, s, xin, hin, lin, \
+                       o0, o1, stat, w, b, eps, rows, D, group, skip)
+    if (nchunk <= 8) VDA_LNS_LAUNCH(8, 1);
+    else if (nchunk <= 16) VDA_LNS_LAUNCH(16, 1);
+    else if (nchunk <= 32) VDA_LNS_LAUNCH(32, 1);
+    else if (nchunk <= 64) VDA_LNS_LAUNCH(64, 1);
+    else if (nchunk <= 128) VDA_LNS_LAUNCH(64, 2);
+    else VDA_LNS_LAUNCH(64, 4);
+#undef VDA_LNS_LAUNCH
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_split_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream) {
+    VDA_REQUIRE(x && hi && lo && stat, "vda_split_stats_f32: null pointer");
+    VDA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)stat & 7) == 0,
+                "vda_split_stats_f32: 16-byte alignment required");
+    return ln_split_launch<0>(x, nullptr, nullptr, (h16*)hi, (h16*)lo, stat, nullptr, nullptr, eps, rows, D, 0, 0, stream);
+}
+
+extern "C" int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const float* w, const float* b, float eps, int rows, int D,
+                                       int group, int skip, vda_stream_t stream) {
+    VDA_REQUIRE(hi && lo && out && w && b, "vda_layernorm_split_f16: null pointer");
+    VDA_REQUIRE(((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)b & 15) == 0,
+                "vda_layernorm_split_f16: 16-byte alignment required");
+    return ln_split_launch<1>(nullptr, (const h16*)hi, (const h16*)lo, (h16*)out, nullptr, nullptr, w, b, eps, rows, D, group, skip, stream);
+}
+
+extern "C" int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, vda_stream_t stream) {
+    VDA_REQUIRE(partial && stat && rows > 0 && np > 0, "vda_ln_stats_finalize: bad arguments");
+    VDA_REQUIRE(((uintptr_t)partial & 7) == 0 && ((uintptr_t)stat & 7) == 0, "vda_ln_stats_finalize: 8-byte alignment required");
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, stat, eps, rows, np);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int vda_fold_ln_weight(const float* W, const float* bias, const float* ln_w, const float* ln_b, void* Wf, float* c1, float* c2, int N,
+                                  int K, vda_stream_t stream) {
+    VDA_REQUIRE(W && ln_w && ln_b && Wf && c1 && c2 && N > 0 && K > 0, "vda_fold_ln_weight: bad arguments");
+    hipLaunchKernelGGL(fold_ln_weight_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, W, bias, ln_w, ln_b, (h16*)Wf, c1, c2, N, K);
+    VDA_LAUNCH_CHECK();
+    return 0;
 }
 
 template <typename T>

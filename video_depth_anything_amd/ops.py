@@ -82,7 +82,7 @@ def zero_page(device):
 
 
 def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, res2=None, gamma=None, pos=None,
-         relu_in=False, conv=None, P=0, convt=None):
+         relu_in=False, conv=None, P=0, convt=None, out2=None, stats=None):
     """out = epilogue(A[M,K] W[N,K]^T). conv = (B,H,W,Cin,Ho,Wo,stride) switches A to the
     implicit 3x3 window of an NHWC tensor; convt = (k, h, w, Cout) for VDA_EPI_CONVT_F16."""
     _act(A, "A"), _req(W, A.dtype, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
@@ -90,6 +90,8 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     a = GemmArgs()
     a.A, a.W, a.bias, a.out = _p(A), _p(W), _p(bias), _p(out)
     a.res, a.res2, a.gamma, a.pos = _p(res), _p(res2), _p(gamma), _p(pos)
+    _req(stats, F32, "stats")
+    a.out2, a.stats = _p(out2), _p(stats)
     a.zero_page = _p(zero_page(A.device))
     a.M, a.N, a.K = M, N, K
     a.lda = K if lda is None else lda
@@ -123,6 +125,32 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     if timed:
         e1.record()
         prof.samples.append((name, 2.0 * M * N * K, e0, e1))
+
+
+def split_stats(x, hi, lo, stat, eps, rows, D):
+    """fp32 rows -> the two fp16 planes of the split residual stream (x = hi + lo) and stat[r] = (mean, rstd)."""
+    _req(x, F32, "x"), _req(hi, F16, "hi"), _req(lo, F16, "lo"), _req(stat, F32, "stat")
+    check(lib.vda_split_stats_f32(_p(x), _p(hi), _p(lo), _p(stat), eps, rows, D, _stream(x)), "vda_split_stats_f32")
+
+
+def ln_stats_finalize(partial, stat, eps, rows, np_):
+    """partial[r, np, 2] (sum, centred sum of squares per 64 columns) -> stat[r] = (mean, rstd)."""
+    _req(partial, F32, "partial"), _req(stat, F32, "stat")
+    check(lib.vda_ln_stats_finalize(_p(partial), _p(stat), eps, rows, np_, _stream(partial)), "vda_ln_stats_finalize")
+
+
+def layernorm_split(hi, lo, out, w, b, eps, rows, D, group=0, skip=0):
+    """LayerNorm of x = hi + lo (fp32 statistics) -> fp16."""
+    _req(hi, F16, "hi"), _req(lo, F16, "lo"), _req(out, F16, "out"), _req(w, F32, "w"), _req(b, F32, "b")
+    check(lib.vda_layernorm_split_f16(_p(hi), _p(lo), _p(out), _p(w), _p(b), eps, rows, D, group, skip, _stream(hi)), "vda_layernorm_split_f16")
+
+
+def fold_ln_weight(W, bias, ln_w, ln_b, Wf, c1, c2, N, K):
+    """Wf = fp16(W * ln_w[None, :]), c1 = Wf.float().sum(1), c2 = bias + W @ ln_b (pack time)."""
+    for t, n in ((W, "W"), (bias, "bias"), (ln_w, "ln_w"), (ln_b, "ln_b"), (c1, "c1"), (c2, "c2")):
+        _req(t, F32, n)
+    _req(Wf, F16, "Wf")
+    check(lib.vda_fold_ln_weight(_p(W), _p(bias), _p(ln_w), _p(ln_b), _p(Wf), _p(c1), _p(c2), N, K, _stream(W)), "vda_fold_ln_weight")
 
 
 def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
