@@ -59,7 +59,7 @@ enum vda_epilogue {
      * The fp32 residual stream x is kept as TWO fp16 planes, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22+ significant
      * bits): the hi plane IS the A operand of the GEMM that consumes LayerNorm(x), so no LayerNorm pass touches memory. */
     VDA_EPI_SCALE_RES_SPLIT = 10,/* x' = (res_h + res2_h) + gamma[n]*(acc + bias[n]); out_h = fp16(x'), out2_h = fp16(x' - out_h) (in place
-                                    over res / res2 is allowed); stats[m, n/64, :] = (sum, centred sum of squares) of x' over the 64
+                                    over res / res2 is allowed); stats[n/64, m, :] = (sum, centred sum of squares) of x' over the 64
                                     columns n/64*64.. (fp32; N % 64 == 0): vda_ln_stats_finalize turns them into (mean, rstd) rows */
     VDA_EPI_LN_BIAS_F16 = 11,    /* A = hi plane, W = W*diag(ln_w) (vda_fold_ln_weight): out_h = rstd[m]*(acc - mean[m]*gamma[n]) + bias[n]
                                     with (mean, rstd) = stats[m, 0:2], gamma = c1 = row sums of the folded W, bias = c2 = b + W.ln_b */
@@ -85,7 +85,7 @@ typedef struct vda_gemm_args {
     /* VDA_EPI_PATCH_F32: P patches per frame. VDA_EPI_CONVT_F16: k, input h, w, Cout */
     int32_t P, tK, tH, tW, tCout;
     void* out2;             /* VDA_EPI_SCALE_RES_SPLIT: lo plane of the result */
-    float* stats;           /* VDA_EPI_SCALE_RES_SPLIT: out, [M, N/64, 2] partial row statistics (may be NULL);
+    float* stats;           /* VDA_EPI_SCALE_RES_SPLIT: out, [N/64, M, 2] partial row statistics;
                                VDA_EPI_LN_*: in, [M, 2] (mean, rstd) */
 } vda_gemm_args;
 
@@ -126,7 +126,7 @@ int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const flo
 /* ---- LayerNorm folded into the neighbouring GEMMs (VDA_EPI_SCALE_RES_SPLIT / VDA_EPI_LN_*; block.py:56,68,105-106)
  * vda_split_stats_f32: fp32 rows x [rows, D] -> the two fp16 planes (hi = fp16(x), lo = fp16(x - hi)) and the row statistics
  *   stat[r] = (mean, rstd = 1/sqrt(var + eps)) (two-pass, fp32): the entry into the split stream after the patch embedding.
- * vda_ln_stats_finalize: partial[r, np, 2] (sum, centred sum of squares per 64 columns, as VDA_EPI_SCALE_RES_SPLIT writes them)
+ * vda_ln_stats_finalize: partial[np, r, 2] (sum, centred sum of squares per 64 columns, as VDA_EPI_SCALE_RES_SPLIT writes them)
  *   -> stat[r] = (mean, rstd), combined in column order (Chan et al.), D = 64*np.
  * vda_layernorm_split_f16: LayerNorm of x = hi + lo (fp32 statistics), fp16 out, group/skip as vda_layernorm_f32_f16 (the taps).
  * vda_fold_ln_weight: pack-time fold of LayerNorm's affine into the Linear that follows it: Wf[n,k] = fp16(W[n,k]*ln_w[k]),

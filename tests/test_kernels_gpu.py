@@ -232,7 +232,7 @@ def test_gemm_split_residual_and_stats(ops, gemm_variant, M, N, K):
     b, gamma, x = rnd(N, seed=145), rnd(N, seed=146), rnd(M, N, seed=147, scale=3.0) + 0.3
     hi0, lo0 = split_planes(x)
     hi, lo = dev(hi0.clone()), dev(lo0.clone())
-    part = torch.full((M, N // 64, 2), float("nan"), device="cuda")
+    part = torch.full((N // 64, M, 2), float("nan"), device="cuda")
     ops.gemm(dev(A), dev(W), hi, _lib.EPI_SCALE_RES_SPLIT, M=M, N=N, K=K, bias=dev(b), gamma=dev(gamma), res=hi, res2=lo, out2=lo, stats=part)
     ref = (hi0.float() + lo0.float()) + gamma * (A.float() @ W.float().t() + b)
     got = hi.float() + lo.float()

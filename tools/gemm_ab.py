@@ -29,6 +29,12 @@ for (M, N, K) in shapes:
             kw.update(res=torch.randn(M, N, device="cuda", generator=g).half())
     if epi in (_lib.EPI_SCALE_RES_F32,):
         kw.update(res=out, gamma=torch.ones(N, device="cuda"))
+    if epi == _lib.EPI_SCALE_RES_SPLIT:
+        lo = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        kw.update(res=out, res2=lo, out2=lo, gamma=torch.ones(N, device="cuda") * 1e-3,
+                  stats=torch.zeros(N // 64, M, 2, device="cuda"))
+    if epi in (_lib.EPI_LN_BIAS_F16, _lib.EPI_LN_GELU_F16):
+        kw.update(gamma=torch.ones(N, device="cuda"), stats=torch.ones(M, 2, device="cuda"))
     ts = {v: [] for v in variants}
     for rep in range(5):
         for v in variants:

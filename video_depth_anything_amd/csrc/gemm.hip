@@ -183,7 +183,7 @@ int launch(const vda_gemm_args& a, hipStream_t s) {
 }
 
 // Partial row statistics of the split stream for the kernels whose epilogue is not row-layout (small problems only):
-// part[m, j, :] = (sum, centred sum of squares) of hi + lo over columns 64j..64j+63, one lane per (row, 64-column block).
+// part[j, m, :] = (sum, centred sum of squares) of hi + lo over columns 64j..64j+63, one lane per (row, 64-column block).
 __global__ void __launch_bounds__(256) split_partials_kernel(const h16* __restrict__ hi, const h16* __restrict__ lo, float* __restrict__ part,
                                                              int M, int N, int ldc) {
     const int np = N >> 6;
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(256) split_partials_kernel(const h16* __restri
         const float d = ((float)a[e] + (float)b[e]) - mean;
         sq = fmaf(d, d, sq);
     }
-    part[2 * i] = sum;
-    part[2 * i + 1] = sq;
+    part[2 * ((size_t)j * M + m)] = sum;
+    part[2 * ((size_t)j * M + m) + 1] = sq;
 }
 
 }  // namespace
@@ -242,7 +242,7 @@ static int launch_small(const vda_gemm_args& a, hipStream_t s) {
     const bool narrow = a.N <= 64;
     if (a.a_mode == VDA_A_DENSE) {
         const int rc = narrow ? launch<128, 64, VDA_A_DENSE>(a, s) : launch<128, 128, VDA_A_DENSE>(a, s);
-        if (rc == 0 && a.epilogue == VDA_EPI_SCALE_RES_SPLIT && a.stats != nullptr) {
+        if (rc == 0 && a.epilogue == VDA_EPI_SCALE_RES_SPLIT) {
             // this kernel's epilogue does not own whole row segments: the partial statistics come from a pass over the planes
             const long long items = (long long)a.M * (a.N >> 6);
             hipLaunchKernelGGL(split_partials_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const h16*)a.out, (const h16*)a.out2, a.stats, a.M,
@@ -299,7 +299,8 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             VDA_REQUIRE(a.N % 32 == 0, "vda_gemm_f16: GEGLU needs N%%32==0");
             break;
         case VDA_EPI_SCALE_RES_SPLIT:
-            VDA_REQUIRE(a.res != nullptr && a.res2 != nullptr && a.out2 != nullptr, "vda_gemm_f16: the split-residual epilogue needs res, res2 (hi / lo planes) and out2");
+            VDA_REQUIRE(a.res != nullptr && a.res2 != nullptr && a.out2 != nullptr && a.stats != nullptr,
+                        "vda_gemm_f16: the split-residual epilogue needs res, res2 (hi / lo planes), out2 and stats");
             VDA_REQUIRE(a.N % 64 == 0 && a.ldc % 8 == 0 && a.a_mode == VDA_A_DENSE, "vda_gemm_f16: the split-residual epilogue needs a dense A operand, N%%64==0 and ldc%%8==0");
             VDA_REQUIRE(((uintptr_t)a.res & 15) == 0 && ((uintptr_t)a.res2 & 15) == 0 && ((uintptr_t)a.out2 & 15) == 0 && ((uintptr_t)a.stats & 7) == 0,
                         "vda_gemm_f16: split-residual planes must be 16-byte aligned");

@@ -219,9 +219,28 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         }
     };
 
+    // LayerNorm-folded epilogues: the (mean, rstd) pairs of the wave's WTM rows (lane -> rows lane, lane + 64) are fetched with
+    // the tile's first K tile, ride through the K loop in 4 VGPRs and are parked in the wave's slice of W slot 1 (idle during the
+    // epilogue) when it starts: the epilogue's row groups then read them from LDS instead of waiting on a global load each
+    // (qkv: +11 us per launch with per-group global loads). The split-residual epilogue uses the same slice the other way:
+    // its partial row statistics are collected there and leave as two 512-byte stores per wave tile.
+    constexpr bool LN_EPI = vda_gemm::is_ln_epi<EPI>;
+    constexpr bool STAT_LDS = LN_EPI || EPI == VDA_EPI_SCALE_RES_SPLIT;
+    static_assert(!STAT_LDS || (WTM <= 128 && W_BYTES >= NW * 1024), "statistics slice: 1 KiB per wave in W slot 1");
+    char* const sst = smem + W_BASE + W_BYTES + wave * 1024;
+    float2 nstat[2] = {float2{0.f, 0.f}, float2{0.f, 0.f}};
+    auto load_stats = [&](int t) {
+        if constexpr (LN_EPI) {
+            const int r0 = (t / nbn) * BM + wm * WTM + lane;
+            nstat[0] = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)min(r0, p.M - 1));
+            if constexpr (WTM > 64) nstat[1] = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)min(r0 + 64, p.M - 1));
+        }
+    };
+
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
     load_bias(tile);
+    load_stats(tile);
     set_sources(tile);
     tap_of(0);
     stage_a(0, 0, smem);
@@ -386,6 +405,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         const int dbg = __builtin_amdgcn_readfirstlane((p.relu_in >> 8) & 0xff);      // A/B switches (vda_gemm_set_variant(5 + 16 * flags))
         if ((dbg & 1) && next < ntiles) {
             load_bias(next);
+            load_stats(next);
             set_sources(next);
             tap_of(0);
             stage_a(0, 0, smem);
@@ -400,6 +420,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         // residual reads and the output stores become contiguous 16-byte accesses covering full 128-byte lines.
         const int bm0 = m0 + wm * WTM, bn0 = n0 + wn * WTN;
         const bool interior = bm0 + WTM <= p.M && bn0 + WTN <= p.N;       // wave-uniform
+        if constexpr (LN_EPI) {
+            *reinterpret_cast<float2*>(sst + lane * 8) = nstat[0];
+            if constexpr (WTM > 64) *reinterpret_cast<float2*>(sst + (64 + lane) * 8) = nstat[1];
+        }
         {
             using RT = vda_gemm::RowTraits<EPI>;
             constexpr int NC = RT::NC, RR = RT::f32_out ? 8 : 4;            // columns per lane, row groups per 32-row block
@@ -433,7 +457,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                     constexpr bool GUARD = decltype(guard)::value;
                     constexpr int NG = RR / RG;                                  // row groups per 32-row block
                     auto load_group = [&](int blk, int r0, vda_gemm::RowAux (&ax)[RG]) {
-                        if (!geglu_idle) {
+                        if constexpr (LN_EPI) {
+#pragma unroll
+                            for (int q = 0; q < RG; ++q) {
+                                const float2 st = *reinterpret_cast<const float2*>(sst + (blk * 32 + (r0 + q) * (32 / RR) + lrow_e) * 8);
+                                ax[q].s0 = st.x;
+                                ax[q].s1 = st.y;
+                            }
+                        } else if (!geglu_idle) {
 #pragma unroll
                             for (int q = 0; q < RG; ++q)
                                 vda_gemm::load_row_aux<EPI, GUARD>(p, bm0 + blk * 32 + (r0 + q) * (32 / RR) + lrow_e, en, ax[q]);
@@ -471,6 +502,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                                     }
                                 }
                                 if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD, false>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
+                                if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT)        // the row's 8 lanes hold the same pair (rows past M: never stored)
+                                    *reinterpret_cast<float2*>(sst + (i * 32 + row) * 8) = float2{aux[g & 1][q].o0, aux[g & 1][q].o1};
                             }
                         }
                     }
@@ -481,11 +514,13 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
                 // Epilogues with row-dependent loads (residual, pos-embed) prefetch after their LAST block instead: with an LDS-DMA
                 // in flight hipcc waits vmcnt(0) - every store included - at each of those loads (dbg bit 2 switches this off)
+                // (the LayerNorm-folded epilogues' 8-byte row statistics do not count: measured -20 us on fc1 with the early prefetch)
                 constexpr bool ROW_AUX = EPI == VDA_EPI_SCALE_RES_F32 || EPI == VDA_EPI_SCALE_RES_F32_H || EPI == VDA_EPI_RES_F16 || EPI == VDA_EPI_PATCH_F32 ||
-                                         EPI == VDA_EPI_SCALE_RES_SPLIT || vda_gemm::is_ln_epi<EPI>;
-                const int pf_block = (ROW_AUX && !(dbg & 4)) ? MI / 2 - 1 : 0;
+                                         EPI == VDA_EPI_SCALE_RES_SPLIT;
+                const int pf_block = ((ROW_AUX && !(dbg & 4)) || (dbg & 8)) ? MI / 2 - 1 : 0;          // dbg 8: A/B, late for every epilogue
                 if (i == pf_block && next < ntiles && !(dbg & 1)) {
                     load_bias(next);
+                    load_stats(next);
                     set_sources(next);
                     tap_of(0);
                     stage_a(0, 0, smem);
@@ -493,6 +528,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                     stage_w(0, smem + W_BASE);
                 }
             }
+        }
+        if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
+            // partial statistics of the wave tile: [column block][row], rows bm0 + lane and bm0 + 64 + lane: two 512-byte runs
+            lgkm0();
+            float* dst = p.stats + ((size_t)(bn0 >> 6) * p.M + bm0) * 2;
+#pragma unroll
+            for (int hh = 0; hh < WTM / 64; ++hh)
+                if (bm0 + hh * 64 + lane < p.M) *reinterpret_cast<float2*>(dst + (hh * 64 + lane) * 2) = *reinterpret_cast<const float2*>(sst + (hh * 64 + lane) * 8);
         }
         // Every wave is done READING its staging slice before the next tile's K tile 1 lands in it: LDS ordering only, so a raw
         // barrier (a __syncthreads here would also drain the stores and the prefetched K tile 0).

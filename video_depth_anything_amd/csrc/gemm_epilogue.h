@@ -219,7 +219,13 @@ struct RowAux {
     f32x4 f0, f1;
     h16x8 h0, h1;
     float s0, s1;        // LayerNorm-folded epilogues: the row's (mean, rstd)
+    mutable float o0, o1;   // VDA_EPI_SCALE_RES_SPLIT: (sum, centred sum of squares) of the row's 64 columns, for the caller to store
 };
+
+// [column block][row] layout of the partial statistics: the 8 rows a wave instruction covers are one 64-byte run
+__device__ __forceinline__ void store_split_stats(const vda_gemm_args& p, int m, int n, const RowAux& x) {
+    *reinterpret_cast<float2*>(p.stats + ((size_t)(n >> 6) * p.M + m) * 2) = float2{x.o0, x.o1};
+}
 
 // GUARD = false: the caller has established that every row / column of the wave's tile is inside the matrix. The bounds
 // test is not free: it puts every row's loads and stores in their own basic block, and hipcc then waits vmcnt(0) at each
@@ -282,19 +288,18 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         const size_t off = (size_t)m * p.ldc + n;
         *reinterpret_cast<h16x8*>((h16*)p.out + off) = oh;
         *reinterpret_cast<h16x8*>((h16*)p.out2 + off) = ol;
-        if (p.stats) {
-            sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-            sum = sum8(sum);
-            const float mean = sum * (1.f / 64.f);
-            float sq = 0.f;
+        // partial statistics of the row's 64 columns (all 8 lanes end up with the same pair); the caller stores them
+        sum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        sum = sum8(sum);
+        const float mean = sum * (1.f / 64.f);
+        float sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float d = v[i] - mean;
-                sq = fmaf(d, d, sq);
-            }
-            sq = sum8(sq);
-            if ((n & 63) == 0) *reinterpret_cast<float2*>(p.stats + ((size_t)m * (p.N >> 6) + (n >> 6)) * 2) = float2{sum, sq};
+        for (int i = 0; i < 8; ++i) {
+            const float d = v[i] - mean;
+            sq = fmaf(d, d, sq);
         }
+        x.o0 = sum;
+        x.o1 = sum8(sq);
     } else if constexpr (EPI == VDA_EPI_BIAS_F16) {
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {

@@ -648,7 +648,7 @@ struct Run {
         auto res_gemm = [&](const void* A, const std::string& wk, const std::string& gk, int K, bool stats_next) -> int {   // x += gamma * (A @ W^T + b)
             vda_gemm_args a = {};
             a.A = A, a.W = W(wk + ".weight"), a.out = thi, a.out2 = tlo, a.res = thi, a.res2 = tlo, a.bias = V(wk + ".bias"), a.gamma = V(gk);
-            a.stats = stats_next ? lnpart : nullptr;
+            a.stats = lnpart;
             a.M = rows, a.N = D, a.K = K, a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_SCALE_RES_SPLIT;
             VDA_TRY(gemm(a));
             if (stats_next && !dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, s));

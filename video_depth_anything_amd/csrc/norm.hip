@@ -312,15 +312,15 @@ __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__
     }
 }
 
-// partial[r, np, 2] = (sum, centred sum of squares) per 64 columns -> stat[r] = (mean, rstd); pairwise update in column order
+// partial[np, r, 2] = (sum, centred sum of squares) per 64 columns -> stat[r] = (mean, rstd); pairwise update in column order
 // (Chan, Golub, LeVeque): no E[x^2] - mean^2 cancellation, fixed order.
 __global__ void __launch_bounds__(256) ln_stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, float eps, int rows, int np) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
-    const float2* p = reinterpret_cast<const float2*>(partial) + (size_t)r * np;
+    const float2* p = reinterpret_cast<const float2*>(partial) + r;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     for (int j = 0; j < np; ++j) {
-        const float2 q = p[j];
+        const float2 q = p[(size_t)j * rows];
         const float mb = q.x * (1.f / 64.f), delta = mb - mean, nn = n + 64.f;
         mean += delta * (64.f / nn);
         m2 += q.y + delta * delta * (n * 64.f / nn);

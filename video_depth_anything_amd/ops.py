@@ -134,7 +134,7 @@ def split_stats(x, hi, lo, stat, eps, rows, D):
 
 
 def ln_stats_finalize(partial, stat, eps, rows, np_):
-    """partial[r, np, 2] (sum, centred sum of squares per 64 columns) -> stat[r] = (mean, rstd)."""
+    """partial[np, r, 2] (sum, centred sum of squares per 64 columns) -> stat[r] = (mean, rstd)."""
     _req(partial, F32, "partial"), _req(stat, F32, "stat")
     check(lib.vda_ln_stats_finalize(_p(partial), _p(stat), eps, rows, np_, _stream(partial)), "vda_ln_stats_finalize")
 
