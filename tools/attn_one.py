@@ -7,10 +7,10 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(32, 1370, 3 * H * 64, device="cuda", generator=g).half()
 o = torch.empty(32, 1370, H * 64, dtype=torch.float16, device="cuda")
 from video_depth_anything_amd import _lib
-for scale in (1.0, 0.3):
+for scale in (0.3,):
     q = (qkv * scale).contiguous()
     for rep in range(3):
-        for variant in (1, 3):
+        for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '1,3,4,5').split(',')]:
             _lib.lib.vda_attention_set_variant(variant)
             for _ in range(2):
                 ops.attention(q, o, 32, 1370, H)

@@ -31,7 +31,12 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ int k_swz(int row) { return (row >> 1) & 7; }          // 16-row conflict-free for 32-row b128 fragments
 __device__ __forceinline__ int v_swz(int row) { return ((row >> 1) & 1) << 2; }   // separates the 4 rows of a tr16 block
 
-template <bool TR, bool PK, bool LSUM = false>
+// MB ("max through the matrix pipe"): Q is pre-scaled by log2(e)/8 and the running reference point m of the online softmax is fed
+// to the score MFMAs as a fifth k-step (K side: a constant [1, 1, 0, ...] row; Q side: [-m_hi, -m_lo, 0, ...], m = m_hi + m_lo in
+// fp16 pairs): the accumulators come out as log2-domain scores MINUS the reference, and p = exp2(acc) needs no per-score fma
+// (31 of the ~155 VALU issues per 64-key tile; the loop is VALU-bound). Any reference point gives the same softmax; m only has
+// to stay within rounding of the running maximum, which its fp16 pair does (22 bits).
+template <bool TR, bool PK, bool LSUM = false, bool MB = false, int ABL = 0>   // ABL: timing ablations (tools/attn_one.py), wrong results
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) attn_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
                                                    int nqb, int total_blocks) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -63,7 +68,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int ks = 0; ks < 4; ++ks) {
             qf[ks] = *reinterpret_cast<const h16x8*>(qp + ks * 16);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = qf[ks][e] * (h16)0.125f;
+            for (int e = 0; e < 8; ++e) qf[ks][e] = MB ? (h16)((float)qf[ks][e] * (0.125f * 1.4426950408889634f)) : qf[ks][e] * (h16)0.125f;
         }
     }
 
@@ -85,7 +90,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = MB ? 0.f : -1e30f, l_run = 0.f;
+    // MB: the fifth k-step's operands. K side: k' = 0, 1 are one (lanes of half h = 0 hold k' = 0..7); Q side: -m as an fp16 pair.
+    h16x8 kone, mneg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        kone[e] = (h16)((h == 0 && e < 2) ? 1.f : 0.f);
+        mneg[e] = (h16)0.f;
+    }
     // LSUM: the softmax denominator comes out of the matrix pipe - one extra MFMA per 16-key step with an all-ones A operand
     // sums the fp16 P the numerator uses - instead of 32 v_add_f32 per tile on the (binding) VALU.
     f32x16 acc_l;
@@ -124,10 +136,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             const char* kp = Kt + row * 128;
             const int sw = k_swz(row);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < (ABL == 5 ? 1 : 4); ++ks) {
                 const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
                 s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
             }
+            if constexpr (MB) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kone, mneg, s[sub], 0, 0, 0);
         }
         // accumulator register e of half `sub` is key  kt*64 + sub*32 + (e&3) + 8*(e>>2) + 4h
         if (__builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0))) {      // scalar branch, last tile only
@@ -141,11 +154,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
         // ---- online softmax (per query = per lane pair {lane, lane^32})
         float mx = s[0][0];
+        if constexpr (ABL != 2) {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
+        if constexpr (MB) {
+            // the accumulators are scores minus the reference m_run (log2 domain): nothing to do while no score exceeds it
+            if (__builtin_amdgcn_readfirstlane((int)(kt == 0 || __ballot(mx > 0.f) != 0ull))) {
+                // new reference = the running maximum rounded to an fp16 pair (lanes whose maximum did not move keep theirs: delta = 0)
+                const float m_want = kt == 0 ? mx : m_run + fmaxf(mx, 0.f);
+                const h16 mh = (h16)m_want, ml = (h16)(m_want - (float)mh);
+                const float m_new = (float)mh + (float)ml;
+                const float delta = m_new - m_run;                     // exact: both are 22-bit values of similar magnitude
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+                if constexpr (LSUM) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc_l[e] *= alpha;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+                m_run = m_new;
+                mneg[0] = h == 0 ? -mh : (h16)0.f;
+                mneg[1] = h == 0 ? -ml : (h16)0.f;
+            }
+        } else {
         const float m_new = fmaxf(m_run, mx);
         // Rescale only when some query's running max moved (alpha == 1 exactly otherwise, so skipping is bit-exact).
         if (__builtin_amdgcn_readfirstlane((int)(__ballot(m_new > m_run) != 0ull))) {
@@ -160,6 +202,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
             m_run = m_new;
+        }
         }
         h16x8 pf[4];
         if constexpr (PK) {
@@ -189,8 +232,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[sub][e], LOG2E, -mb));
-                    if constexpr (!LSUM) ps[e & 3] += pv;
+                    const float arg = MB ? s[sub][e] : fmaf(s[sub][e], LOG2E, -mb);
+                    const float pv = ABL == 1 ? arg : __builtin_amdgcn_exp2f(arg);
+                    if constexpr (!LSUM && ABL != 3) ps[e & 3] += pv;
                     pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
                 }
             if constexpr (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
@@ -223,7 +267,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                         vf[j] = *reinterpret_cast<const h16*>(Vt + key * 128 + ((((ch >> 3) ^ v_swz(key))) << 4) + ((ch & 7) << 1));
                     }
                 }
-                acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
+                if constexpr (ABL == 4) acc_o[c][kstep] += (float)vf[0] * (float)pf[kstep][c];
+                else acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
             }
         }
         cur ^= 1;
@@ -264,7 +309,17 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
     VDA_REQUIRE((long long)N * 3 * heads * HD < (1ll << 31), "vda_attention_f16: one frame's qkv exceeds 32-bit element offsets");
     hipStream_t s = (hipStream_t)stream;
-    if (g_attn_variant == 3)
+#define VDA_ATTN_ABL(K)                                                                                                                        \
+    if (g_attn_variant == 10 + K)                                                                                                              \
+        hipLaunchKernelGGL((attn_kernel<true, false, false, false, K>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total); \
+    else
+    VDA_ATTN_ABL(1) VDA_ATTN_ABL(2) VDA_ATTN_ABL(3) VDA_ATTN_ABL(4) VDA_ATTN_ABL(5)
+#undef VDA_ATTN_ABL
+    if (g_attn_variant == 4)
+        hipLaunchKernelGGL((attn_kernel<true, false, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 5)
+        hipLaunchKernelGGL((attn_kernel<true, false, true, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 3)
         hipLaunchKernelGGL((attn_kernel<true, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 1)
         hipLaunchKernelGGL((attn_kernel<true, false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
