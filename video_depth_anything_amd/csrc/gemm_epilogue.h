@@ -268,10 +268,8 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
     if constexpr (is_ln_epi<EPI>) {
         // LayerNorm applied AFTER the GEMM: acc = sum_k hi[m,k] * (W[n,k] * ln_w[k]); c.gamma = c1 (row sums of the folded W), c.bias = c2
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = fmaf(x.s1, fmaf(-x.s0, c.gamma[i], v[i]), c.bias[i]);
-            if constexpr (EPI == VDA_EPI_LN_GELU_F16) v[i] = gelu_erf(v[i]);
-        }
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(x.s1, fmaf(-x.s0, c.gamma[i], v[i]), c.bias[i]);
+        if constexpr (EPI == VDA_EPI_LN_GELU_F16) gelu_erf_n(v);
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
         // the row's 64 columns of this wave tile sit in 8 consecutive lanes (all inside the matrix together: N % 64 == 0)
@@ -303,8 +301,7 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
     } else if constexpr (EPI == VDA_EPI_BIAS_F16) {
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+        gelu_erf_n(v);
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
 #pragma unroll
@@ -327,8 +324,13 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
         // n is a VALUE column group (n % 32 < 16); g holds columns n+16.. (the gates)
+        if constexpr (BIAS) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf(BIAS ? g[i] + c.gbias[i] : g[i]);
+            for (int i = 0; i < 8; ++i) g[i] += c.gbias[i];
+        }
+        gelu_erf_n(g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= g[i];
         store8h((h16*)p.out + (size_t)m * p.ldc + ((n >> 5) * 16 + (n & 15)), v);
     } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
         const int k = p.tK, Co = p.tCout;

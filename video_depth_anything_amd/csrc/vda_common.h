@@ -51,20 +51,67 @@ __device__ __forceinline__ float erf_as(float x) {
     const float r = fmaf(-p, e, 1.0f);
     return copysignf(r, x);
 }
-// gelu(x) = 0.5 x (1 + erf(x/sqrt2)). With erf(|z|) = 1 - p(t) e^{-z^2} (same A-S 7.1.26 polynomial, 0.5 folded into its
-// coefficients, z = |x|/sqrt2 folded into t's slope and the exponent's scale):  gelu(x) = max(x, 0) - |x| * 0.5 p(t) * e^{-x^2/2}.
-// No copysign / 1+erf / 0.5x: 13 VALU issues per element instead of 17 (this runs 128x per lane per fc1 tile: ~20 % of that GEMM).
+// gelu(x) = 0.5 x (1 + erf(x/sqrt2)) = max(x, 0) - |x| * 0.5 erfc(|x|/sqrt2), and 0.5 erfc(|x|/sqrt2) = P(|x|)^-16 with a
+// degree-6 polynomial P: the form of Abramowitz-Stegun 7.1.28, coefficients refitted here for the weight |x| (minimax over
+// |x| in [0, 12], tools/gelu_fit.py: 2.2e-7 absolute in exact arithmetic, 6.0e-7 evaluated in fp32; relative error where
+// |gelu| > 1e-3: 2.2e-4, half an fp16 ulp of the stored result). ONE transcendental (v_rcp_f32) per element instead of the two
+// (rcp + exp) of the A-S 7.1.26 form this replaces: each costs as much as ~6 plain VALU issues in the fc1 epilogue, which runs
+// this 128 times per lane and tile (measured there: 64 us of a 420 us launch, 15 us of them per transcendental).
+#define VDA_GELU_C0 1.04427485e+00f
+#define VDA_GELU_C1 5.20639309e-02f
+#define VDA_GELU_C2 2.21137954e-02f
+#define VDA_GELU_C3 3.37046981e-03f
+#define VDA_GELU_C4 7.53152628e-05f
+#define VDA_GELU_C5 3.96599537e-05f
+#define VDA_GELU_C6 6.98591262e-06f
 __device__ __forceinline__ float gelu_erf(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-    p = fmaf(p, t, 0.5f * 1.421413741f);
-    p = fmaf(p, t, 0.5f * -0.284496736f);
-    p = fmaf(p, t, 0.5f * 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
-    // explicit fma: the guarded and the branch-free epilogue instantiations must round identically (a row's result may not
-    // depend on which tile it falls in), so nothing is left to -ffp-contract's per-instance choice
-    return fmaf(-(ax * (p * t)), e, fmaxf(x, 0.f));
+    // explicit fma everywhere: every instantiation (scalar here, packed below, guarded / branch-free epilogues) must round
+    // identically - a row's result may not depend on which tile or kernel it falls in
+    float p = fmaf(VDA_GELU_C6, ax, VDA_GELU_C5);
+    p = fmaf(p, ax, VDA_GELU_C4);
+    p = fmaf(p, ax, VDA_GELU_C3);
+    p = fmaf(p, ax, VDA_GELU_C2);
+    p = fmaf(p, ax, VDA_GELU_C1);
+    p = fmaf(p, ax, VDA_GELU_C0);
+    float r = __builtin_amdgcn_rcpf(p);
+    r *= r;
+    r *= r;
+    r *= r;
+    r *= r;
+    return fmaf(-ax, r, fmaxf(x, 0.f));
+}
+
+// The same arithmetic on two elements per instruction (v_pk_fma_f32 / v_pk_mul_f32, twice the scalar rate while the matrix pipe
+// is idle, as it is in an epilogue). Every operation is the IEEE operation of the scalar form in the same order: bit-identical.
+typedef float vda_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vda_f32x2 gelu_erf2(vda_f32x2 x) {
+    const vda_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+#define VDA_P2(c) vda_f32x2{c, c}
+    vda_f32x2 p = __builtin_elementwise_fma(VDA_P2(VDA_GELU_C6), ax, VDA_P2(VDA_GELU_C5));
+    p = __builtin_elementwise_fma(p, ax, VDA_P2(VDA_GELU_C4));
+    p = __builtin_elementwise_fma(p, ax, VDA_P2(VDA_GELU_C3));
+    p = __builtin_elementwise_fma(p, ax, VDA_P2(VDA_GELU_C2));
+    p = __builtin_elementwise_fma(p, ax, VDA_P2(VDA_GELU_C1));
+    p = __builtin_elementwise_fma(p, ax, VDA_P2(VDA_GELU_C0));
+#undef VDA_P2
+    vda_f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    r *= r;
+    r *= r;
+    r *= r;
+    r *= r;
+    const vda_f32x2 relu = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return __builtin_elementwise_fma(-ax, r, relu);
+}
+template <int N>
+__device__ __forceinline__ void gelu_erf_n(float (&v)[N]) {
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int i = 0; i < N; i += 2) {
+        const vda_f32x2 r = gelu_erf2(vda_f32x2{v[i], v[i + 1]});
+        v[i] = r[0];
+        v[i + 1] = r[1];
+    }
 }
 
 // 16-byte async global -> LDS copy. The LDS destination is the wave-uniform `lds_base`
