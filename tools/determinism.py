@@ -39,6 +39,25 @@ repeat("qkv", lambda o: ops.gemm(A1, W[(3072, 1024)], o, _lib.EPI_BIAS_F16, M=M,
 repeat("proj in-place", lambda o: ops.gemm(A1, W[(1024, 1024)], o, _lib.EPI_SCALE_RES_F32, M=M, N=1024, K=1024, bias=b1024, gamma=b1024, res=o), lambda: tok0.clone())
 repeat("fc1 gelu", lambda o: ops.gemm(A1, W[(4096, 1024)], o, _lib.EPI_BIAS_GELU_F16, M=M, N=4096, K=1024, bias=b4096), lambda: torch.zeros(M, 4096, dtype=F16, device="cuda"))
 repeat("fc2 in-place", lambda o: ops.gemm(A4, W[(1024, 4096)], o, _lib.EPI_SCALE_RES_F32, M=M, N=1024, K=4096, bias=b1024, gamma=b1024, res=o), lambda: tok0.clone())
+# LayerNorm-folded forms: split residual stream in place (hi plane is `o`; lo and the partial statistics are compared too) and the
+# epilogues that consume (mean, rstd)
+lo0, hi0 = rn(M, 1024, scale=1e-3), rn(M, 1024)
+c1, stat = rn(4096, dtype=F32), rn(M, 2, dtype=F32)
+for nm, A_, K_ in (("proj split", A1, 1024), ("fc2 split", A4, 4096)):
+    keep = {}
+    def run(o, A_=A_, K_=K_, keep=keep):
+        lo, part = lo0.clone(), torch.zeros(16, M, 2, device="cuda")
+        ops.gemm(A_, W[(1024, K_)], o, _lib.EPI_SCALE_RES_SPLIT, M=M, N=1024, K=K_, bias=b1024, gamma=b1024, res=o, res2=lo, out2=lo, stats=part)
+        torch.cuda.synchronize()
+        for key, t in (("lo", lo), ("part", part)):
+            if key in keep and not torch.equal(keep[key], t):
+                global bad
+                bad += 1
+                print(nm, key, "differs", flush=True)
+            keep.setdefault(key, t.clone())
+    repeat(nm, run, lambda: hi0.clone())
+repeat("qkv ln", lambda o: ops.gemm(A1, W[(3072, 1024)], o, _lib.EPI_LN_BIAS_F16, M=M, N=3072, K=1024, bias=b3072, gamma=c1, stats=stat), lambda: torch.zeros(M, 3072, dtype=F16, device="cuda"))
+repeat("fc1 ln gelu", lambda o: ops.gemm(A1, W[(4096, 1024)], o, _lib.EPI_LN_GELU_F16, M=M, N=4096, K=1024, bias=b4096, gamma=c1, stats=stat), lambda: torch.zeros(M, 4096, dtype=F16, device="cuda"))
 # temporal module shapes
 Mt = 11552
 At = rn(Mt, 1024)
@@ -92,5 +111,12 @@ if len(sys.argv) > 2:
         if not torch.equal(ref, d):
             bad += 1
             print("forward run", it, "differs: max", float((ref - d).abs().max()), "first differing stages:", msg, flush=True)
+    # the handle's launch sequence (LayerNorm folded into the GEMMs, the product path)
+    href = m.forward(x, fp32=False).clone()
+    for it in range(3):
+        if not torch.equal(href, m.forward(x, fp32=False)):
+            bad += 1
+            print("vda_forward run", it, "differs", flush=True)
+    print("vda_forward repeats done", flush=True)
 print("TOTAL bad =", bad)
 sys.exit(1 if bad else 0)
