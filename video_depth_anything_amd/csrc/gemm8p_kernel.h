@@ -67,7 +67,18 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     const int ntiles = nbm * nbn;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int per_xcd = nwg >> 3;                                    // launch guarantees nwg % 8 == 0
-    auto tile_of = [&](int round) { return round * nwg + (bid & 7) * per_xcd + (bid >> 3); };
+    // The LAST, partial round (ntiles % nwg tiles) is dealt to the XCDs in groups of nbn consecutive tiles (one row panel), round
+    // robin, so that every XCD keeps the same share of busy CUs instead of whole XCDs going idle (needs nbn | per_xcd; otherwise
+    // the plain mapping stays). A workgroup without a tile in that round has one tile time of slack: see the stagger below.
+    const int full_rounds = ntiles / nwg, rem = ntiles - full_rounds * nwg;
+    const bool deal_last = rem > 0 && full_rounds > 0 && per_xcd % nbn == 0;
+    auto tile_of = [&](int round) {
+        if (deal_last && round == full_rounds) {
+            const int slot = bid >> 3, j = ((slot / nbn) * 8 + (bid & 7)) * nbn + slot % nbn;
+            return j < rem ? round * nwg + j : ntiles;
+        }
+        return round * nwg + (bid & 7) * per_xcd + (bid >> 3);
+    };
 
     // ---- per-lane DMA sources. A piece is 8 rows x 128 B; lane -> (row lrow of the piece, LDS chunk lane & 7).
     // The swizzled source chunk ((lane&7) ^ ((row>>1)&7)) does not depend on the piece index (pieces are 8 rows
@@ -239,6 +250,15 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
 
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
+    // Stagger: all workgroups run the same tile time, so their epilogues hit HBM together (a plain fp16 epilogue stores at
+    // 7.8 TB/s aggregate: it is bandwidth-bound only because it is synchronised). Workgroups that sit out the last round start
+    // up to 3/4 of a tile time late, in four phases - for free, the launch ends with the others' last tile - and take their
+    // epilogues out of phase with the rest. Tile time estimate: 1.6 us per K tile + 8 us, at ~2.1 GHz, in 64-cycle sleep units.
+    if (!((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // switch off: variant 5 + 16 * 16
+        const int q = (bid >> 3) & 3;
+        const int units = (nt * 52 + 260) * q / 4;
+        for (int i = 0; i < units; i += 120) __builtin_amdgcn_s_sleep(120);
+    }
     load_bias(tile);
     load_stats(tile);
     set_sources(tile);
