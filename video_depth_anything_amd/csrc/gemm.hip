@@ -367,9 +367,11 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     }
     if (big) {
         vda_gemm_args a8 = a;
+        static const int stagger = getenv("VDA_GEMM_STAGGER") ? atoi(getenv("VDA_GEMM_STAGGER")) : 1;      // A/B hook: 0 = no start stagger
+        if (!stagger) a8.relu_in |= 16 << 8;
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
-        const int rc = !eight ? (small_mfma ? vda_gemm256s_launch(a, big, s) : vda_gemm256_launch(a, big, s))
+        const int rc = !eight ? (small_mfma ? vda_gemm256s_launch(a8, big, s) : vda_gemm256_launch(a, big, s))
                        : big == 128 ? (a.a_mode == VDA_A_DENSE ? vda_gemm8p_dense_bn128(a8, s) : vda_gemm8p_conv_bn128(a8, s))
                        : a.a_mode == VDA_A_DENSE ? (sched8 ? vda_gemm8p_dense_bn256_sched(a8, s, sched8) : vda_gemm8p_dense_bn256(a8, s))
                                                  : vda_gemm8p_conv_bn256(a8, s);

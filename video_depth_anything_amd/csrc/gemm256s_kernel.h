@@ -52,7 +52,16 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
     const int ntiles = nbm * nbn;
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int per_xcd = nwg >> 3;                                    // launch guarantees nwg % 8 == 0
-    auto tile_of = [&](int round) { return round * nwg + (bid & 7) * per_xcd + (bid >> 3); };
+    // last partial round dealt evenly to the XCDs in row-panel groups, as in gemm8p_kernel.h
+    const int full_rounds = ntiles / nwg, rem = ntiles - full_rounds * nwg;
+    const bool deal_last = rem > 0 && full_rounds > 0 && per_xcd % nbn == 0;
+    auto tile_of = [&](int round) {
+        if (deal_last && round == full_rounds) {
+            const int slot = bid >> 3, j = ((slot / nbn) * 8 + (bid & 7)) * nbn + slot % nbn;
+            return j < rem ? round * nwg + j : ntiles;
+        }
+        return round * nwg + (bid & 7) * per_xcd + (bid >> 3);
+    };
 
     // ---- per-lane DMA sources. A piece is 8 rows x 128 B; lane -> (row lrow of the piece, LDS chunk lane & 7).
     // The swizzled source chunk ((lane&7) ^ ((row>>1)&7)) does not depend on the piece index (pieces are 8 rows
@@ -164,6 +173,12 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
 
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
+    // stagger of the workgroups that sit out the last round (gemm8p_kernel.h): up to 3/4 of a tile time, four phases, free
+    if (!((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // VDA_GEMM_STAGGER=0 switches it off
+        const int q = (bid >> 3) & 3;
+        const int units = (nt * 60 + 260) * q / 4;
+        for (int i = 0; i < units; i += 120) __builtin_amdgcn_s_sleep(120);
+    }
     set_sources(tile);
     tap_of(0);
     stage(0, smem);
