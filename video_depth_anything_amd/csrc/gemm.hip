@@ -216,6 +216,7 @@ int vda_gemm256s_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_dense_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm256s_dense_bn128_bm192(const vda_gemm_args& a, hipStream_t s);      // 192 x 128 tiles, six waves; -1 = epilogue not built
 
 // gemm8p_*.hip: 256 x 256 tile, 8-phase two-group schedule
 int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
@@ -341,7 +342,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     bool eight = g_gemm_variant >= 5 && (g_gemm_variant & 15) == 5;      // upper bits: A/B switches of the 8-phase kernel
     if (eight) big = 256;
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
-    if (g_gemm_variant == 2 || g_gemm_variant == 4) big = 128;
+    if (g_gemm_variant == 2 || g_gemm_variant == 4 || g_gemm_variant == 8) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
     if (g_gemm_variant == 9) {               // 9 = 256x128 8-phase two-group schedule
         eight = true;
@@ -371,6 +372,31 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         if (!stagger) a8.relu_in |= 16 << 8;
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
+        // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles
+        // (ViT-S proj / fc2: 3 against 2.25; variant 8 forces them). Only the one-barrier 256 x 128 family has the shape.
+        bool tall192 = g_gemm_variant == 8 && a.a_mode == VDA_A_DENSE;
+        if (g_gemm_variant < 0 && !eight && big == 128 && a.a_mode == VDA_A_DENSE) {
+            static thread_local int ncu = 0;
+            if (ncu == 0) {
+                int dev = 0, cu = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+                ncu = cu < 8 ? 8 : (cu & ~7);
+            }
+            const long long nbn = (a.N + 127) / 128;
+            const long long r256 = (((a.M + 255) / 256) * nbn + ncu - 1) / ncu, r192 = (((a.M + 191) / 192) * nbn + ncu - 1) / ncu;
+            static const int allow192 = getenv("VDA_GEMM_BM192") ? atoi(getenv("VDA_GEMM_BM192")) : 1;
+            tall192 = allow192 && r192 * 3 * 100 < r256 * 4 * 85;                 // at least 15 % fewer tile-time units (a 192-row tile costs ~0.8, not 0.75, of a 256-row one)
+        }
+        if (tall192) {
+            const int rc192 = vda_gemm256s_dense_bn128_bm192(a8, s);
+            if (rc192 >= 0) {
+                static thread_local char name192[64];
+                snprintf(name192, sizeof(name192), "gemm256s_kernel<128, %d, %d, 192>", a.a_mode, a.epilogue);
+                g_last_kernel = name192;
+                return rc192;
+            }
+        }
         const int rc = !eight ? (small_mfma ? vda_gemm256s_launch(a8, big, s) : vda_gemm256_launch(a, big, s))
                        : big == 128 ? (a.a_mode == VDA_A_DENSE ? vda_gemm8p_dense_bn128(a8, s) : vda_gemm8p_conv_bn128(a8, s))
                        : a.a_mode == VDA_A_DENSE ? (sched8 ? vda_gemm8p_dense_bn256_sched(a8, s, sched8) : vda_gemm8p_dense_bn256(a8, s))

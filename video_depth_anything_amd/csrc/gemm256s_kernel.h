@@ -25,18 +25,20 @@ namespace vda_gemm256s {
 
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;
-constexpr int BM = 256;
-constexpr int NW = 8;                 // waves
-constexpr int NT = NW * 64;
-
-template <int BN, int AMODE, int EPI>
-__global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
+// BM = 256 on 8 waves, or (BN = 128 only) BM = 192 on 6 waves (3 x 2, the same 64 x 64 wave tile): the tile for problems whose
+// 256-row tile count sits just above a multiple of the CU count - ViT-S's proj / fc2: 172 x 3 = 516 tiles = 2.016 rounds run as
+// 3; 229 x 3 = 687 tiles of 3/4 the size = 2.68 rounds run as 3 x 0.75 = 2.25.
+template <int BN, int AMODE, int EPI, int BM = 256>
+__global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_args p) {
+    static_assert(BM == 256 || (BM == 192 && BN == 128), "tile heights: 256, or 192 with BN = 128");
+    constexpr int NW = BM / 32;                    // waves: 8, or 6
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
     constexpr int WM = NW / WN;                    // waves along M
     constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile: 128x64 (BN=256) or 64x64 (BN=128)
     constexpr int MI = WTM / 16, NJ = WTN / 16;    // 16x16 subtiles per wave
     constexpr int MH = MI / 2;                       // subtiles per half of the wave's rows (pipeline unit)
-    constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;   // 1-KiB DMA pieces per wave
+    constexpr int AJ = BM / 8 / NW, WP = BN / 8, WJ = (WP + NW - 1) / NW;   // 1-KiB DMA pieces per wave (W: dealt round robin, guarded when NW does not divide them)
+    static_assert((BM / 8) % NW == 0 && NW % 2 == 0, "A pieces per wave; the swizzle constant needs an even wave count");
     constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES, STAGE = A_BYTES + W_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,6 +136,7 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
         }
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
+            if (WP % NW != 0 && wave + NW * j >= WP) break;                  // wave-uniform
             const int n = min(tn0 + (wave + NW * j) * 8 + lrow, p.N - 1);
             glds16((const h16*)p.W + (size_t)(unsigned)(n * p.K + src_chk + k0), buf + A_BYTES + (wave + NW * j) * 1024);
         }
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
 
     const int nt = p.K / BK;
     static_assert(WTN == 64, "epilogue staging assumes a 64-column wave tile");
-    // epilogue staging (8 waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
+    // epilogue staging (NW waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
     constexpr int STG_OFF = (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
     char* stg = smem + STG_OFF + wave * 8192;
 
@@ -350,18 +353,18 @@ __global__ void __launch_bounds__(NT) gemm256s_kernel(const vda_gemm_args p) {
     }
 }
 
-template <int BN, int AMODE, int EPI>
+template <int BN, int AMODE, int EPI, int BM = 256>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
-    constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + 8 * 8192;
+    constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + BM / 32 * 8192;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static VdaKernelDeviceState dev_state;
-    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI>), smem, dev_state);
+    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI, BM>), smem, dev_state);
     if (num_cu < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI>), dim3(grid), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI, BM>), dim3(grid), dim3(BM / 32 * 64), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
@@ -383,6 +386,20 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
         case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT>(a, s);
         case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16>(a, s);
         case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16>(a, s);
+        default: break;
+    }
+    return -1;
+}
+
+// 192-row tiles (BN = 128, dense A): the epilogues the encoder uses
+inline int launch_dense_bm192(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_BIAS_F16, 192>(a, s);
+        case VDA_EPI_BIAS_GELU_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_BIAS_GELU_F16, 192>(a, s);
+        case VDA_EPI_SCALE_RES_F32: return launch256<128, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32, 192>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<128, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT, 192>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 192>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_LN_GELU_F16, 192>(a, s);
         default: break;
     }
     return -1;
