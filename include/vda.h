@@ -288,6 +288,9 @@ int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, 
 /* Parity hook: copy `bytes` of a named intermediate of the last forward ("tap0".."tap3", "l1", "l2", "l3t", "l4t", "p4t",
  * "p3t", "p2", "p1"; activation dtype of that forward's precision, channels padded to multiples of 64) to device `dst`. */
 int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream);
+/* Test utility: occupy `wgs` workgroups (256 threads, lds_bytes of LDS each) for about `cycles` shader clocks on `stream` - a
+ * stand-in for a communication kernel running beside the forward (tools/contention.py). Bounded: every wave leaves by itself. */
+int vda_debug_occupy(int wgs, int lds_bytes, long long cycles, vda_stream_t stream);
 /* Launch-sequence switches (A/B and cross-checks). "residual_in_ln" (default 0; fp16 path only): 1 = attn.proj / mlp.fc2 store
  * their output as fp16 and the residual add runs inside the following LayerNorm (vda_layernorm_residual_f32_f16); 0 = the add
  * is the GEMM's fp32 in-place epilogue (VDA_EPI_SCALE_RES_F32; measured 2 % faster end to end). Changes the workspace size. */

@@ -87,6 +87,7 @@ SIGNATURES = {
     "vda_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "vda_debug_copy": (_i, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
     "vda_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "vda_debug_occupy": (_i, [_i, _i, _ll, _vp]),
     "vda_profile_start": (_i, [_vp, _i]),
     "vda_profile_stop": (_i, [_vp, C.c_char_p, _i]),
 }
