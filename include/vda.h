@@ -93,8 +93,12 @@ int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
 /* fp32-operand twin (v_mfma_f32_32x32x2_f32, exact fp32): A, W, res, res2 and out are fp32; K % 16 == 0, conv Cin % 16 == 0.
  * The epilogue ids keep their meaning (what is fused); every "_F16" output / residual is fp32 here. */
 int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
-/* Tuning hook: -1 (default) picks the tile per shape; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 tiles on
- * 32x32x16 MFMA; 3 / 4 = the same tiles on 16x16x32 MFMA (what -1 uses for wide N). */
+/* Tuning / A-B hook (process-wide): -1 (default) picks the kernel per shape; 0 = 128-row tiles; 1 / 2 = 256x256 / 256x128 tiles on
+ * 32x32x16 MFMA; 3 / 4 = the same tiles on 16x16x32 MFMA, one barrier per K tile; 5 = 256x256 8-phase two-group schedule (what -1
+ * uses for wide N), 5 + 16*flags = the same with debug switches (gemm8p_kernel.h: 1 early next-tile prefetch, 2 clock stamps,
+ * 4 / 8 prefetch placement, 16 no start stagger), 5 + 32*s = K-loop schedule s; 7 = patch-in-LDS direct 3x3 conv where it
+ * applies; 8 = 192x128 tiles on six waves; 9 = 256x128 8-phase. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
+ * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 1, 1). */
 int vda_gemm_set_variant(int v);
 /* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
 const char* vda_gemm_last_kernel(void);
@@ -152,7 +156,9 @@ int vda_groupnorm_nhwc_f32(const float* in, float* out, const float* w, const fl
 int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream);
 /* fp32-operand twin: qkv fp32 [B, N, 3, heads, 64] -> out fp32 [B, N, heads*64], every product on fp32 MFMA. */
 int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda_stream_t stream);
-/* Debug cross-check: 1 (default) = V^T fragments via ds_read_b64_tr_b16, 0 = scalar LDS reads. */
+/* A-B hook: 1 (default) = V^T fragments via ds_read_b64_tr_b16, scalar softmax math; 2 = packed fp32 softmax math; 0 = scalar LDS
+ * reads of V (cross-check); 3 = row sums through the matrix pipe; 4 / 5 = running max through the matrix pipe (without / with 3);
+ * 10 + k = timing ablations (WRONG results: no exp / max / row sums / PV MFMAs / 1 of 4 QK k-steps), tools/attn_one.py. */
 int vda_attention_set_variant(int v);
 
 /* Temporal attention across T frames per pixel (motion_module.py:232-295,
