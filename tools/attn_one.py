@@ -9,7 +9,7 @@ o = torch.empty(32, 1370, H * 64, dtype=torch.float16, device="cuda")
 from video_depth_anything_amd import _lib
 for scale in (0.3,):
     q = (qkv * scale).contiguous()
-    for rep in range(3):
+    for rep in range(int(os.environ.get('ATTN_REPS', '3'))):
         for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '1,3,4,5').split(',')]:
             _lib.lib.vda_attention_set_variant(variant)
             for _ in range(2):
