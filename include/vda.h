@@ -158,6 +158,7 @@ int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_s
 int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda_stream_t stream);
 /* A-B hook: 1 (default) = V^T fragments via ds_read_b64_tr_b16, scalar softmax math; 2 = packed fp32 softmax math; 0 = scalar LDS
  * reads of V (cross-check); 3 = row sums through the matrix pipe; 4 / 5 = running max through the matrix pipe (without / with 3);
+ * 7 = software-pipelined form (next tile's score MFMAs inside the softmax; three waves per SIMD);
  * 10 + k = timing ablations (WRONG results: no exp / max / row sums / PV MFMAs / 1 of 4 QK k-steps), tools/attn_one.py. */
 int vda_attention_set_variant(int v);
 

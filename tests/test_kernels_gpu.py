@@ -330,7 +330,7 @@ def attn_ref(qkv, B, N, H):
     return (a @ v).transpose(1, 2).reshape(B, N, H * 64)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 0, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 0, 4, 5, 7])
 @pytest.mark.parametrize("B,N,H", [(2, 13, 2), (1, 64, 1), (2, 200, 3), (1, 1370, 2)])
 def test_attention(ops, B, N, H, variant):
     from video_depth_anything_amd._lib import lib

@@ -290,6 +290,194 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Software-pipelined form (variant 7): the score MFMAs of key tile t+1 are issued inside the softmax of tile t, so a wave has
+// matrix work and VALU work in the same stretch of its instruction stream instead of alternating between the two (the
+// ablations in DESIGN.md: the loop runs as MFMA time PLUS softmax time). Costs a second set of score accumulators (32 VGPRs:
+// three waves per SIMD instead of four) and a third K slot (K two tiles ahead, V one): 40 KiB of LDS per workgroup.
+// Same instructions on the same operands in the same order per query as attn_kernel<true, false>: bit-identical results.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) attn_pipe_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N,
+                                                                                              int H, int nqb, int total_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];          // K0 K1 K2 | V0 V1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = total_blocks >> 3, rm = total_blocks & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int bh = t / nqb, qb = t - bh * nqb;
+    const int b = bh / H, head = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;
+    const unsigned rs32 = (unsigned)rs;
+    const h16* Qb = qkv + (size_t)b * N * rs + head * HD;
+    const h16* Kb = Qb + (size_t)H * HD;
+    const h16* Vb = Kb + (size_t)H * HD;
+    const int q_row = qb * BQ + wave * 32 + r;
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(qb * BQ + wave * 32 < N)) != 0;
+    h16x8 qf[4];
+    {
+        const h16* qp = Qb + (size_t)min(q_row, N - 1) * rs + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const h16x8*>(qp + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = qf[ks][e] * (h16)0.125f;
+        }
+    }
+    const int lrow = lane >> 3, lpos = lane & 7;
+    auto stage_k = [&](int kt, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j, row = piece * 8 + lrow;
+            const unsigned key = (unsigned)min(kt * BKV + row, N - 1) * rs32;
+            glds16(Kb + (key + ((lpos ^ k_swz(row)) << 3)), buf + piece * 1024);
+        }
+    };
+    auto stage_v = [&](int kt, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j, row = piece * 8 + lrow;
+            const unsigned key = (unsigned)min(kt * BKV + row, N - 1) * rs32;
+            glds16(Vb + (key + ((lpos ^ v_swz(row)) << 3)), buf + piece * 1024);
+        }
+    };
+    auto qk = [&](const char* Kt, f32x16 (&s)[2]) {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+            const int row = sub * 32 + r;
+            const char* kp = Kt + row * 128;
+            const int sw = k_swz(row);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[sub], 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int nt = (N + BKV - 1) / BKV;
+    char* const Ks = smem;
+    char* const Vs = smem + 3 * TILE_BYTES;
+    stage_k(0, Ks);
+    stage_v(0, Vs);
+    if (nt > 1) stage_k(1, Ks + TILE_BYTES);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sc[2];
+    if (wave_active) qk(Ks, sc);
+    else {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[sub][e] = 0.f;
+    }
+    int kn = 1;                                             // K slot of tile kt + 1
+    for (int kt = 0; kt < nt; ++kt) {
+        if (kt > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // K(kt+1), V(kt) landed (issued an iteration ago)
+            __syncthreads();                                      // ... for every wave; and everyone is done with tile kt-1's slots
+        }
+        const int k2 = kn == 2 ? 0 : kn + 1;                       // slot of K(kt+2) = the one K(kt-1) had
+        if (kt + 2 < nt) stage_k(kt + 2, Ks + k2 * TILE_BYTES);
+        if (kt + 1 < nt) stage_v(kt + 1, Vs + ((kt + 1) & 1) * TILE_BYTES);
+        const char* Kn = Ks + kn * TILE_BYTES;
+        const char* Vt = Vs + (kt & 1) * TILE_BYTES;
+        kn = k2;
+        if (!wave_active) continue;
+        if (__builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0))) {
+            const int kbase = kt * BKV + 4 * h;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase + sub * 32 + (e & 3) + 8 * (e >> 2) >= N) sc[sub][e] = -1e30f;
+        }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sc[sub][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(m_new > m_run) != 0ull))) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+            m_run = m_new;
+        }
+        // ---- one stretch: scores of tile kt+1 (matrix pipe) | exp / sums / conversion of tile kt (VALU) | P.V of tile kt
+        // (after the last tile the next-tile MFMAs run on a stale K slot and their result is dropped: no branch, one basic block)
+        f32x16 sn[2];
+        qk(Kn, sn);
+        h16x8 pf[4];
+        const float mb = m_run * LOG2E;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sc[sub][e], LOG2E, -mb));
+                ps[e & 3] += pv;
+                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+            }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+        for (int kstep = 0; kstep < 4; ++kstep) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h16x8 vf;
+                const int i = lane & 15, qq = i >> 2, pp = i & 3;
+                const int col = c * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int key = kstep * 16 + half * 8 + 4 * h + qq;
+                    const char* ap = Vt + key * 128 + ((((col >> 3) ^ v_swz(key))) << 4) + ((col & 7) << 1);
+                    const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((VDA_LDS_AS fp16x4_t*)ap);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vf[half * 4 + e] = (h16)v4[e];
+                }
+                acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
+            }
+        }
+        // issue order of the stretch: every matrix instruction followed by a slice of the softmax's VALU / transcendental work
+        // (16 MFMAs, ~150 VALU): the 8 score MFMAs of the next tile first (their operands are ready), the 8 P.V ones as their P slices
+        // complete
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);       // nine VALU / transcendental
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // two LDS reads
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) sc[sub] = sn[sub];
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < N) {
+        h16* op = out + ((size_t)b * N + q_row) * ((size_t)H * HD) + head * HD + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o = {(h16)(acc_o[c][4 * g + 0] * inv), (h16)(acc_o[c][4 * g + 1] * inv),
+                           (h16)(acc_o[c][4 * g + 2] * inv), (h16)(acc_o[c][4 * g + 3] * inv)};
+                *reinterpret_cast<h16x4*>(op + c * 32 + 8 * g) = o;
+            }
+    }
+}
+
 }  // namespace
 
 static int g_attn_variant = 1;   // 1: ds_read_b64_tr_b16 V fragments + scalar softmax math (3 % faster than packed, tools/attn_one.py);
@@ -315,7 +503,9 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     else
     VDA_ATTN_ABL(1) VDA_ATTN_ABL(2) VDA_ATTN_ABL(3) VDA_ATTN_ABL(4) VDA_ATTN_ABL(5)
 #undef VDA_ATTN_ABL
-    if (g_attn_variant == 4)
+    if (g_attn_variant == 7)
+        hipLaunchKernelGGL(attn_pipe_kernel, dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 4)
         hipLaunchKernelGGL((attn_kernel<true, false, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 5)
         hipLaunchKernelGGL((attn_kernel<true, false, true, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
