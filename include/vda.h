@@ -98,7 +98,7 @@ int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
  * uses for wide N), 5 + 16*flags = the same with debug switches (gemm8p_kernel.h: 1 early next-tile prefetch, 2 clock stamps,
  * 4 / 8 prefetch placement, 16 no start stagger), 5 + 32*s = K-loop schedule s; 7 = patch-in-LDS direct 3x3 conv where it
  * applies; 8 = 192x128 tiles on six waves; 9 = 256x128 8-phase. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
- * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 1, 1). */
+ * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 0, 1). */
 int vda_gemm_set_variant(int v);
 /* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
 const char* vda_gemm_last_kernel(void);

@@ -368,8 +368,9 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
     }
     if (big) {
         vda_gemm_args a8 = a;
-        static const int stagger = getenv("VDA_GEMM_STAGGER") ? atoi(getenv("VDA_GEMM_STAGGER")) : 1;      // A/B hook: 0 = no start stagger
+        static const int stagger = getenv("VDA_GEMM_STAGGER") ? atoi(getenv("VDA_GEMM_STAGGER")) : 0;      // 1 / 2 = start stagger (off: see gemm8p_kernel.h)
         if (!stagger) a8.relu_in |= 16 << 8;
+        if (stagger == 2) a8.relu_in |= 32 << 8;             // A/B: panel-aligned phases
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
         // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles

@@ -178,7 +178,9 @@ __global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_a
     if (tile >= ntiles) return;                        // uniform per workgroup
     // stagger of the workgroups that sit out the last round (gemm8p_kernel.h): up to 3/4 of a tile time, four phases, free
     if (!((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // VDA_GEMM_STAGGER=0 switches it off
-        const int q = (bid >> 3) & 3;
+        // phase by slot: the nbn workgroups of an XCD that share an A row panel land in DIFFERENT phases (keeping them in phase -
+        // VDA_GEMM_STAGGER=2 - is slower than no stagger at all: it is those neighbours' epilogues that collide)
+        const int q = ((p.relu_in >> 8) & 32) ? ((bid >> 3) / (nbn <= 8 ? nbn : 8)) & 3 : (bid >> 3) & 3;
         const int units = (nt * 60 + 260) * q / 4;
         for (int i = 0; i < units; i += 120) __builtin_amdgcn_s_sleep(120);
     }

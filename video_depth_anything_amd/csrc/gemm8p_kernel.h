@@ -250,12 +250,17 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
 
     int tile = tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
-    // Stagger: all workgroups run the same tile time, so their epilogues hit HBM together (a plain fp16 epilogue stores at
-    // 7.8 TB/s aggregate: it is bandwidth-bound only because it is synchronised). Workgroups that sit out the last round start
-    // up to 3/4 of a tile time late, in four phases - for free, the launch ends with the others' last tile - and take their
-    // epilogues out of phase with the rest. Tile time estimate: 1.6 us per K tile + 8 us, at ~2.1 GHz, in 64-cycle sleep units.
+    // Start stagger (VDA_GEMM_STAGGER=1, OFF by default). All workgroups run the same tile time, so their epilogues hit HBM
+    // together (a plain fp16 epilogue stores at 7.8 TB/s aggregate: it is bandwidth-bound only because it is synchronised).
+    // Workgroups that sit out the last round can start up to 3/4 of a tile time late, in four phases, for free - the launch ends
+    // with the others' last tile - and take their epilogues out of phase: -4..-6 us per qkv / fc1 / fc2 launch on some boxes,
+    // nothing on others, and it costs L2 sharing (PMC: +40 % fetched bytes, the workgroups of an XCD no longer read the same W
+    // and A tiles at the same moment) and 2 % with two clips in flight (a sleeping workgroup holds a CU the other stream's
+    // kernel could use). Tile time estimate: 1.6 us per K tile + 8 us, at ~2.1 GHz, in 64-cycle sleep units.
     if (!((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // switch off: variant 5 + 16 * 16
-        const int q = (bid >> 3) & 3;
+        // phase by slot: the nbn workgroups of an XCD that share an A row panel land in DIFFERENT phases (keeping them in phase -
+        // VDA_GEMM_STAGGER=2 - is slower than no stagger at all: it is those neighbours' epilogues that collide)
+        const int q = ((p.relu_in >> 8) & 32) ? ((bid >> 3) / (nbn <= 8 ? nbn : 8)) & 3 : (bid >> 3) & 3;
         const int units = (nt * 52 + 260) * q / 4;
         for (int i = 0; i < units; i += 120) __builtin_amdgcn_s_sleep(120);
     }

@@ -116,6 +116,7 @@ struct ProfSample {
 };
 struct Profile {
     int every = 0;
+    double min_flops = 0.0;                  // launches below it are counted, never bracketed (vda_set_option "profile_min_gflop")
     std::map<std::array<int, 5>, int> seen;
     std::map<std::string, std::pair<long long, double>> launches;      // kernel name -> (launches, algorithmic flops)
     std::vector<ProfSample> samples;
@@ -481,7 +482,7 @@ struct Run {
         if (pf.every <= 0) return prec == VDA_PREC_F32 ? vda_gemm_f32(&a, s) : vda_gemm_f16(&a, s);
         const std::array<int, 5> key = {a.M, a.N, a.K, a.epilogue, a.a_mode};
         const int n = pf.seen[key]++;
-        const bool timed = n % pf.every == 0;
+        const bool timed = n % pf.every == 0 && 2.0 * a.M * a.N * a.K >= pf.min_flops;
         ProfSample smp;
         if (timed) {
             VDA_HIP(hipEventCreate(&smp.e0));
@@ -1019,6 +1020,10 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
         h->layouts.clear();                  // the workspace layout depends on it
         return 0;
     }
+    if (strcmp(name, "profile_min_gflop") == 0) {       // vda_profile_start brackets only launches of at least this many GFLOP
+        h->prof.min_flops = 1e9 * value;
+        return 0;
+    }
     if (strcmp(name, "ln_fold") == 0) {
         h->ln_fold = value;
         h->layouts.clear();
@@ -1032,8 +1037,10 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
 extern "C" int vda_profile_start(vda_model* h, int every) {
     VDA_REQUIRE(h && every > 0, "vda_profile_start: bad arguments");
     VDA_REQUIRE(h->prof.samples.empty(), "vda_profile_start: a profile is already open");
+    const double keep = h->prof.min_flops;
     h->prof = Profile();
     h->prof.every = every;
+    h->prof.min_flops = keep;
     return 0;
 }
 
