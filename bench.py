@@ -146,6 +146,10 @@ def main():
     T, H, W = 32, 518, 518
     x = torch.randn(1, T, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)   # resident in HBM
 
+    if world > 1:
+        # the per-step all-gather runs beside the next step's kernels: with dynamic tile draws a GEMM that finds part of the GPU
+        # taken by the communication kernel loses those CUs, not a whole shift of tiles (tools/contention.py)
+        model.engine.set_option("dyn_sched", 1)
     fwd = lambda: model.forward(x, fp32=args.fp32)          # explicit precision: a bare model(x) follows torch.autocast
     for _ in range(args.warmup):
         fwd()

@@ -87,6 +87,9 @@ typedef struct vda_gemm_args {
     void* out2;             /* VDA_EPI_SCALE_RES_SPLIT: lo plane of the result */
     float* stats;           /* VDA_EPI_SCALE_RES_SPLIT: out, [N/64, M, 2] partial row statistics;
                                VDA_EPI_LN_*: in, [M, 2] (mean, rstd) */
+    int32_t* sched;         /* NULL, or eight int32 counters ZEROED before the launch (one per XCD): the 8-phase kernel then draws its
+                               tiles dynamically - a launch that shares the GPU with another kernel degrades by the CUs it lost,
+                               not by a whole shift of tiles. Other kernels ignore it. Results do not depend on it. */
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);

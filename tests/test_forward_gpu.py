@@ -316,6 +316,34 @@ def test_residual_in_layernorm_matches_the_epilogue_residual():
     assert torch.equal(a, py.forward(x, fp32=False)), "both orchestrations, residual-in-LayerNorm form"
 
 
+def test_dynamic_tile_schedule_does_not_change_the_forward():
+    """vda_set_option "dyn_sched" (what multi-rank runs turn on: the 8-phase GEMMs draw their tiles from per-launch counters zeroed
+    at the start of the forward) moves tiles between workgroups, never a bit of the result."""
+    m, _, _ = model_for("vits", 11)
+    x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(74)).cuda()
+    a = m.forward(x, fp32=False).clone()
+    m.engine.set_option("dyn_sched", 1)
+    try:
+        b = m.forward(x, fp32=False).clone()
+        g = torch.cuda.CUDAGraph()                        # the per-forward counter reset is a memset node: still capturable
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())     # (one workspace slot: the forwards must not overlap)
+        with torch.cuda.stream(side):
+            m.forward(x, fp32=False)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            c = m.forward(x, fp32=False)
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(a, c), f"graph replay with dynamic draws: {int((a != c).sum())} elements differ"
+    finally:
+        m.engine.set_option("dyn_sched", 0)
+    assert torch.equal(a, b), f"eager forward with dynamic draws: {int((a != b).sum())} elements differ"
+    d = m.forward(x, fp32=False)
+    assert torch.equal(a, d), f"static schedule again: {int((a != d).sum())} elements differ"
+
+
 def test_steady_state_forward_is_graph_capturable_and_allocation_free():
     """include/vda.h: after the first forward of a (shape, precision) vda_forward only enqueues kernels on the stream it is
     given - so it can be captured into a HIP graph, and the replay reproduces the eager result bit for bit."""
@@ -323,6 +351,7 @@ def test_steady_state_forward_is_graph_capturable_and_allocation_free():
     x = torch.randn(1, 4, 3, 70, 84, generator=torch.Generator().manual_seed(76)).cuda()
     ref = m.forward(x, fp32=False).clone()               # first use: layout, pos-embed, workspace
     side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())        # (one workspace slot: the forwards must not overlap)
     with torch.cuda.stream(side):
         m.forward(x, fp32=False)
     torch.cuda.synchronize()

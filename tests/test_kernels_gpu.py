@@ -267,6 +267,30 @@ def test_gemm_layernorm_folded(ops, gemm_variant, M, N, K):
         close(out, fn(ref), rtol=3e-3, atol=6e-3, what=f"LayerNorm-folded GEMM epilogue {epi}")
 
 
+def test_gemm_dynamic_tile_schedule_is_result_neutral(ops):
+    """vda_gemm_args.sched (eight zeroed counters: the 8-phase kernel draws its tiles dynamically) changes which workgroup computes
+    which tile, never a result - also when another kernel holds part of the GPU while it runs."""
+    from video_depth_anything_amd import _lib
+    for (M, N, K, epi) in ((43840, 1024, 1024, _lib.EPI_BIAS_F16), (9000, 3072, 256, _lib.EPI_BIAS_GELU_F16), (700, 256, 128, _lib.EPI_BIAS_F16),
+                           (43840, 256, 64, _lib.EPI_BIAS_F16)):
+        A, W, b = dev(rnd(M, K, seed=160).to(F16)), dev(rnd(N, K, seed=161, scale=K ** -0.5).to(F16)), dev(rnd(N, seed=162))
+        ref = torch.empty(M, N, dtype=F16, device="cuda")
+        ops.gemm(A, W, ref, epi, M=M, N=N, K=K, bias=b)
+        side = torch.cuda.Stream()
+        for hog in (0, 24):
+            out = torch.full((M, N), float("nan"), dtype=F16, device="cuda")
+            ctr = torch.zeros(8, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            if hog:
+                _lib.lib.vda_debug_occupy(hog, 16384, int(2e6), side.cuda_stream)        # ~1 ms on 24 CUs beside the GEMM
+            ops.gemm(A, W, out, epi, M=M, N=N, K=K, bias=b, sched=ctr)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), f"M={M} N={N} K={K} hog={hog}: {int((out != ref).sum())} elements differ"
+            if M >= 2048 and N >= 192:      # the 8-phase kernel ran: every tile beyond the workgroups' first was drawn from a counter
+                tiles = -(-M // 256) * -(-N // 256)
+                assert int(ctr.sum()) >= max(0, tiles - 256), (int(ctr.sum()), tiles)
+
+
 # ---------------------------------------------------------------- norms
 @pytest.mark.parametrize("D,rows", [(384, 50), (1024, 37), (128, 9), (64, 130)])
 def test_layernorm(ops, D, rows):

@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
         ("cB", C.c_int32), ("cH", C.c_int32), ("cW", C.c_int32), ("cCin", C.c_int32),
         ("cHo", C.c_int32), ("cWo", C.c_int32), ("cStride", C.c_int32),
         ("P", C.c_int32), ("tK", C.c_int32), ("tH", C.c_int32), ("tW", C.c_int32), ("tCout", C.c_int32),
-        ("out2", C.c_void_p), ("stats", C.c_void_p),
+        ("out2", C.c_void_p), ("stats", C.c_void_p), ("sched", C.c_void_p),
     ]
 
 

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(NT) gemm256_kernel(const vda_gemm_args p) {
                                 }
                                 if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
                                 if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {      // all 8 lanes of the row store the same pair: no divergence
-                                    if (!GUARD || bm0 + i * 32 + row < p.M) vda_gemm::store_split_stats(p, bm0 + i * 32 + row, en, aux[g & 1][q]);
+                                    if (!GUARD || (bm0 + i * 32 + row < p.M && en < p.N)) vda_gemm::store_split_stats(p, bm0 + i * 32 + row, en, aux[g & 1][q]);
                                 }
                             }
                         }

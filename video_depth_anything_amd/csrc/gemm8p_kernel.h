@@ -80,6 +80,20 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         return round * nwg + (bid & 7) * per_xcd + (bid >> 3);
     };
 
+    // DYNAMIC tile schedule (p.sched != NULL: eight zeroed int32 counters, one per XCD). XCD x owns the contiguous tile range
+    // [xb, xb + xc); a workgroup starts on tile xb + (its slot) and draws every further tile from the XCD's counter, so a workgroup
+    // that starts late - because another kernel (a second stream's GEMM, a communication kernel) held its CU - simply takes fewer
+    // tiles instead of running its fixed share one shift late: with the static walk a foreign kernel costs ~35 % of its active
+    // time (tools/contention.py). The draw for tile i+2 is issued by lane 0 of wave 0 at the top of tile i+1 ... i.e. one tile
+    // ahead of its use, and handed to the other waves through LDS at the K loop's last barrier.
+    const bool dyn = p.sched != nullptr;
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+    const int xb = (bid & 7) * xq + min(bid & 7, xr), xc = xq + ((bid & 7) < xr ? 1 : 0);
+    const bool drawer = dyn && wave == 0;                          // wave-uniform
+    int fetched = 0;
+    volatile VDA_LDS_AS int* const sched_slot =
+        (volatile VDA_LDS_AS int*)(smem + 3 * BM * ROW_BYTES + BN * ROW_BYTES + NW * 1024);      // W slot 1, past the statistics slices
+
     // ---- per-lane DMA sources. A piece is 8 rows x 128 B; lane -> (row lrow of the piece, LDS chunk lane & 7).
     // The swizzled source chunk ((lane&7) ^ ((row>>1)&7)) does not depend on the piece index (pieces are 8 rows
     // apart, the swizzle has period 16 rows and the wave stride is 64 rows), so it is one lane constant.
@@ -248,7 +262,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         }
     };
 
-    int tile = tile_of(0);
+    // the draw: index (inside the XCD's range) of the tile after next; the youngest vector-memory operation of wave 0 when issued
+    auto draw = [&]() {
+        // (built with -mllvm -amdgpu-atomic-optimizer-strategy=None, build.py: the optimizer would broadcast the uniform result at
+        // once, behind an s_waitcnt vmcnt(0) that also drains the LDS-DMA just issued; as a plain returning atomic the compiler waits
+        // for it where `fetched` is first read - after the K loop - and keeps every copy of it behind that wait)
+        if (drawer && lane == 0) fetched = __hip_atomic_fetch_add(p.sched + (bid & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    int tile = dyn ? ((bid >> 3) < xc ? xb + (bid >> 3) : ntiles) : tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
     // Start stagger (VDA_GEMM_STAGGER=1, OFF by default). All workgroups run the same tile time, so their epilogues hit HBM
     // together (a plain fp16 epilogue stores at 7.8 TB/s aggregate: it is bandwidth-bound only because it is synchronised).
@@ -257,7 +278,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // nothing on others, and it costs L2 sharing (PMC: +40 % fetched bytes, the workgroups of an XCD no longer read the same W
     // and A tiles at the same moment) and 2 % with two clips in flight (a sleeping workgroup holds a CU the other stream's
     // kernel could use). Tile time estimate: 1.6 us per K tile + 8 us, at ~2.1 GHz, in 64-cycle sleep units.
-    if (!((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // switch off: variant 5 + 16 * 16
+    if (!dyn && !((p.relu_in >> 8) & 16) && rem > 0 && full_rounds > 0 && tile_of(full_rounds) >= ntiles) {       // switch off: variant 5 + 16 * 16
         // phase by slot: the nbn workgroups of an XCD that share an A row panel land in DIFFERENT phases (keeping them in phase -
         // VDA_GEMM_STAGGER=2 - is slower than no stagger at all: it is those neighbours' epilogues that collide)
         const int q = ((p.relu_in >> 8) & 32) ? ((bid >> 3) / (nbn <= 8 ? nbn : 8)) & 3 : (bid >> 3) & 3;
@@ -313,13 +334,18 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             stage_a(1, 2, smem + A_BYTES);
             if constexpr (SCHED == 1) {
                 stage_w(1, smem + W_BASE + W_BYTES, 0, WH);         // the second half of W's rows of K tile 1 follows in phase 1
-                vm_wait_keep<AJ + WH>();
+                draw();
+                if (drawer) vm_wait_keep<AJ + WH + 1>();            // (the draw stays in flight with K tile 1)
+                else vm_wait_keep<AJ + WH>();
             } else {
                 stage_w(1, smem + W_BASE + W_BYTES);
-                vm_wait_keep<AJ + WJ>();                                  // K tile 0 landed (mine); K tile 1 stays in flight
+                draw();
+                if (drawer) vm_wait_keep<AJ + WJ + 1>();
+                else vm_wait_keep<AJ + WJ>();                             // K tile 0 landed (mine); K tile 1 stays in flight
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            draw();
         }
         bar();                                  // ... and everyone's
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 1] = __builtin_readcyclecounter();
@@ -421,12 +447,21 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
             sa = sa == 2 ? 0 : sa + 1;
         }
+        if (drawer) {                           // hand the drawn index to the other waves (W slot 1 is idle: every read of the K loop is done)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the draw has landed (nothing else is in flight here)
+            if (lane == 0) *sched_slot = fetched + per_xcd;
+            lgkm0();
+        }
         if (grp == 0) bar();                    // re-align the two groups: every wave is past its last MFMA section's reads
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 2] = __builtin_readcyclecounter();
         // Nobody reads the pipeline buffers any more. The NEXT tile's first K tile is issued after the first 32-row block of
         // the epilogue (below): early enough that the rest of the epilogue covers its HBM/L2 latency, late enough that the
         // epilogue's own first loads (column constants, residual rows) do not queue behind it on the in-order vmcnt.
-        const int next = tile_of(round + 1);
+        int next = tile_of(round + 1);
+        if (dyn) {
+            const int idx = __builtin_amdgcn_readfirstlane(*sched_slot);
+            next = idx < xc ? xb + idx : ntiles;
+        }
         const int dbg = __builtin_amdgcn_readfirstlane((p.relu_in >> 8) & 0xff);      // A/B switches (vda_gemm_set_variant(5 + 16 * flags))
         if ((dbg & 1) && next < ntiles) {
             load_bias(next);
@@ -560,7 +595,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             float* dst = p.stats + ((size_t)(bn0 >> 6) * p.M + bm0) * 2;
 #pragma unroll
             for (int hh = 0; hh < WTM / 64; ++hh)
-                if (bm0 + hh * 64 + lane < p.M) *reinterpret_cast<float2*>(dst + (hh * 64 + lane) * 2) = *reinterpret_cast<const float2*>(sst + (hh * 64 + lane) * 8);
+                if (bm0 + hh * 64 + lane < p.M && bn0 < p.N) *reinterpret_cast<float2*>(dst + (hh * 64 + lane) * 2) = *reinterpret_cast<const float2*>(sst + (hh * 64 + lane) * 8);      // (wave tiles past N hold nothing)
         }
         // Every wave is done READING its staging slice before the next tile's K tile 1 lands in it: LDS ordering only, so a raw
         // barrier (a __syncthreads here would also drain the stores and the prefetched K tile 0).

@@ -123,6 +123,7 @@ struct Profile {
 };
 
 struct Layout {
+    int gemm_launches = 0;                                      // GEMM / conv launches of one forward (dynamic-schedule counters)
     std::map<std::string, std::pair<size_t, size_t>> bufs;      // name -> (offset, bytes)
     std::vector<std::string> order;
     size_t total = 0;
@@ -150,6 +151,8 @@ struct vda_model {
     std::array<int, 5> last_key = {0, 0, 0, 0, -1};
     Profile prof;
     int residual_in_ln = 0;                   // vda_set_option("residual_in_ln"): see Run::forward (off: measured slower end to end)
+    int dyn_sched = 0;                        // vda_set_option("dyn_sched"): dynamic tile draw in the 8-phase GEMM (vda_gemm_args.sched); for
+                                              // processes that share the GPU with communication kernels (multi-rank runs turn it on)
     int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
 };
 
@@ -452,6 +455,8 @@ struct Run {
     Layout* lay;
     hipStream_t s;
     size_t ab;                // bytes per activation element
+    int32_t* sched = nullptr; // dynamic-schedule counters: 8 per GEMM launch of the forward, zeroed at its start
+    int nsched = 0;           // launches so far (dry pass: the count that sizes the block)
 
     void* buf(const std::string& name, size_t elems, size_t esize) {
         const size_t bytes = (elems * esize + 255) & ~(size_t)255;
@@ -474,6 +479,10 @@ struct Run {
     const float* V(const std::string& k) const { return dry ? nullptr : h->vec.at(k); }
 
     int gemm(vda_gemm_args a) {
+        if (prec == VDA_PREC_F16 && h->dyn_sched) {
+            if (!dry && sched != nullptr) a.sched = sched + 8 * nsched;
+            ++nsched;
+        }
         if (dry) return 0;
         a.zero_page = h->zero_page;
         if (a.lda == 0) a.lda = a.K;
@@ -602,6 +611,13 @@ struct Run {
         const vda_config& c = h->cfg;
         const int BT = B * T, ph = H / PATCH, pw = Wd / PATCH;
         const int P = ph * pw, D = c.embed_dim, NH = c.num_heads, Nt = P + 1, rows = BT * Nt;
+        // dynamic-schedule counters of every GEMM launch below: sized by the dry pass, zeroed here once per forward
+        if (prec == VDA_PREC_F16 && h->dyn_sched) {
+            const int cap = dry ? 4096 : lay->gemm_launches;
+            sched = (int32_t*)buf("sched", (size_t)8 * (cap > 0 ? cap : 1), 4);
+            if (!dry) VDA_HIP(hipMemsetAsync(sched, 0, (size_t)32 * lay->gemm_launches, s));
+            nsched = 0;
+        }
         // ---- encoder (dinov2.py:212-219, dinov2_layers/block.py:105-106)
         void* a0 = act("a0", (size_t)BT * P * KPATCH);
         if (!dry) {
@@ -805,6 +821,7 @@ int get_layout(vda_model* h, int B, int T, int H, int W, int prec, Layout** out)
         Layout lay;
         Run r{h, prec, true, &lay, nullptr, prec == VDA_PREC_F32 ? (size_t)4 : (size_t)2};
         VDA_TRY(r.forward(nullptr, nullptr, B, T, H, W));
+        lay.gemm_launches = r.nsched;
         size_t off = 0;
         for (const std::string& n : lay.order) {
             lay.bufs[n].first = off;
@@ -1012,7 +1029,7 @@ static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_
     return 0;
 }
 
-// Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1): see Run::forward.
+// Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1), "dyn_sched" (default 0): see Run::forward.
 extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     VDA_REQUIRE(h && name, "vda_set_option: null argument");
     if (strcmp(name, "residual_in_ln") == 0) {
@@ -1022,6 +1039,11 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     }
     if (strcmp(name, "profile_min_gflop") == 0) {       // vda_profile_start brackets only launches of at least this many GFLOP
         h->prof.min_flops = 1e9 * value;
+        return 0;
+    }
+    if (strcmp(name, "dyn_sched") == 0) {
+        h->dyn_sched = value;
+        h->layouts.clear();
         return 0;
     }
     if (strcmp(name, "ln_fold") == 0) {

@@ -43,6 +43,8 @@ class ModelHandle:
         self._ws = {}                            # workspace blocks by slot (a caller keeping two forwards in flight uses two)
         if os.environ.get("VDA_RESIDUAL_IN_LN") is not None:          # A/B switch for tools / bench runs
             _check(lib.vda_set_option(h, b"residual_in_ln", int(os.environ["VDA_RESIDUAL_IN_LN"])), "vda_set_option")
+        if os.environ.get("VDA_DYN_SCHED") is not None:
+            _check(lib.vda_set_option(h, b"dyn_sched", int(os.environ["VDA_DYN_SCHED"])), "vda_set_option")
         if os.environ.get("VDA_LN_FOLD") is not None:
             _check(lib.vda_set_option(h, b"ln_fold", int(os.environ["VDA_LN_FOLD"])), "vda_set_option")
         self.loaded = False

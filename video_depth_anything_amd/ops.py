@@ -82,7 +82,7 @@ def zero_page(device):
 
 
 def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, res2=None, gamma=None, pos=None,
-         relu_in=False, conv=None, P=0, convt=None, out2=None, stats=None):
+         relu_in=False, conv=None, P=0, convt=None, out2=None, stats=None, sched=None):
     """out = epilogue(A[M,K] W[N,K]^T). conv = (B,H,W,Cin,Ho,Wo,stride) switches A to the
     implicit 3x3 window of an NHWC tensor; convt = (k, h, w, Cout) for VDA_EPI_CONVT_F16."""
     _act(A, "A"), _req(W, A.dtype, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
@@ -91,7 +91,7 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     a.A, a.W, a.bias, a.out = _p(A), _p(W), _p(bias), _p(out)
     a.res, a.res2, a.gamma, a.pos = _p(res), _p(res2), _p(gamma), _p(pos)
     _req(stats, F32, "stats")
-    a.out2, a.stats = _p(out2), _p(stats)
+    a.out2, a.stats, a.sched = _p(out2), _p(stats), _p(sched)
     a.zero_page = _p(zero_page(A.device))
     a.M, a.N, a.K = M, N, K
     a.lda = K if lda is None else lda

@@ -127,6 +127,9 @@ class VideoDepthAnything:
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
         mine = list(shard_windows(len(plan), world, rank))
+        # multi-rank: the per-round all-gather runs beside the next windows' kernels - GEMMs that find CUs taken by it should lose
+        # those CUs, not a whole shift of tiles (dynamic tile draw)
+        eng.set_option("dyn_sched", 1 if world > 1 else 0)
 
         # The uint8 frames THIS rank's windows read (frame 0, the previous window's key frame and its own 30 frames each -
         # SURVEY.md section 8e) live in HBM in a compact buffer, and each crosses PCIe once - not all up front: what the next
