@@ -310,7 +310,7 @@ def test_residual_in_layernorm_matches_the_epilogue_residual():
         m.engine.set_option("ln_fold", 1)
     e = rel_l1(a.cpu().numpy(), b.cpu().numpy())
     record("vits.residual_in_ln_vs_epilogue", e)
-    assert 0 < e < 1.4e-3           # measured 6.5e-4; each form is 6.4e-4 / 6.7e-4 from the fp32 oracle on this input (tools/res_ab.py)
+    assert 0 < e < 1.4e-3           # measured 6.5e-4; each form is 6.4e-4 / 6.7e-4 from the fp32 oracle on this input (tests/diag_res_ab.py)
     py = m.python_engine()
     py.residual_in_ln = True
     assert torch.equal(a, py.forward(x, fp32=False)), "both orchestrations, residual-in-LayerNorm form"
