@@ -14,6 +14,8 @@ if conv:      # head convs: 3x3, 256 -> 256 channels on 32 frames of 148^2 / 74^
     shapes = [(32 * 148 * 148, 256, 2304), (32 * 74 * 74, 256, 2304), (32 * 37 * 37, 256, 2304), (32 * 296 * 296, 128, 2304)]
     if os.environ.get("AB_SHAPES") == "vits":
         shapes = [(32 * 148 * 148, 64, 576), (32 * 74 * 74, 64, 576), (32 * 296 * 296, 64, 576), (32 * 148 * 148, 64, 1152)]
+    if os.environ.get("AB_SHAPES") == "small":        # the head's low-occupancy convs: 19^2 and 37^2 maps
+        shapes = [(32 * 19 * 19, 256, 9216), (32 * 19 * 19, 256, 2304), (32 * 37 * 37, 256, 9216), (32 * 37 * 37, 256, 2304)]
 g = torch.Generator(device="cuda").manual_seed(0)
 for (M, N, K) in shapes:
     A = torch.randn(M, K if not conv else K // 9, device="cuda", generator=g).half()

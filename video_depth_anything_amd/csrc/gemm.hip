@@ -376,18 +376,27 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles
         // (ViT-S proj / fc2: 3 against 2.25; variant 8 forces them). Only the one-barrier 256 x 128 family has the shape.
         bool tall192 = g_gemm_variant == 8 && a.a_mode == VDA_A_DENSE;
+        static thread_local int ncu = 0;
+        if (ncu == 0) {
+            int dev = 0, cu = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+            ncu = cu < 8 ? 8 : (cu & ~7);
+        }
         if (g_gemm_variant < 0 && !eight && big == 128 && a.a_mode == VDA_A_DENSE) {
-            static thread_local int ncu = 0;
-            if (ncu == 0) {
-                int dev = 0, cu = 0;
-                (void)hipGetDevice(&dev);
-                (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-                ncu = cu < 8 ? 8 : (cu & ~7);
-            }
             const long long nbn = (a.N + 127) / 128;
             const long long r256 = (((a.M + 255) / 256) * nbn + ncu - 1) / ncu, r192 = (((a.M + 191) / 192) * nbn + ncu - 1) / ncu;
             static const int allow192 = getenv("VDA_GEMM_BM192") ? atoi(getenv("VDA_GEMM_BM192")) : 1;
             tall192 = allow192 && r192 * 3 * 100 < r256 * 4 * 85;                 // at least 15 % fewer tile-time units (a 192-row tile costs ~0.8, not 0.75, of a 256-row one)
+        }
+        // Few large tiles leave most of the chip idle for a whole K loop: when the 256-row tiling fills at most half of the CUs the
+        // 128-row kernel (four times the tiles, two workgroups per CU) is faster - the head's 19x19 maps: rn4 (46 tiles, K = 9216)
+        // 223 -> 133 us, the refinenet4 convs 62 -> 39 us (tools/gemm_ab.py, AB_SHAPES=small). VDA_GEMM_SMALL_GRID=0 switches it off.
+        static const int small_grid = getenv("VDA_GEMM_SMALL_GRID") ? atoi(getenv("VDA_GEMM_SMALL_GRID")) : 1;
+        if (g_gemm_variant < 0 && small_grid && ((long long)(a.M + 255) / 256) * ((a.N + big - 1) / big) * 2 <= ncu) {
+            g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
+                                                    : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
+            return launch_small(a, s);
         }
         if (tall192) {
             const int rc192 = vda_gemm256s_dense_bn128_bm192(a8, s);
