@@ -128,7 +128,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # VDA_BENCH_FORCE_DIST=1: initialise the process group and run the exchange even at world size 1 - the only way to put the
+    # RCCL calls themselves (init with device_id, all_gather_into_tensor, all_reduce, barrier) through a one-GPU box
+    if world > 1 or os.environ.get("VDA_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)       # NCCL == RCCL over xGMI on ROCm
@@ -146,7 +148,7 @@ def main():
     T, H, W = 32, 518, 518
     x = torch.randn(1, T, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)   # resident in HBM
 
-    if world > 1:
+    if dist is not None:
         # the per-step all-gather runs beside the next step's kernels: with dynamic tile draws a GEMM that finds part of the GPU
         # taken by the communication kernel loses those CUs, not a whole shift of tiles (tools/contention.py)
         model.engine.set_option("dyn_sched", 1)
@@ -154,7 +156,7 @@ def main():
     for _ in range(args.warmup):
         fwd()
     outs = torch.empty(args.steps, T, H, W, dtype=torch.float32, device=dev)
-    gathered = torch.empty(args.steps, world, T, H, W, dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty(args.steps, world, T, H, W, dtype=torch.float32, device=dev) if dist is not None else None
 
     def exchange(s):
         """The one exchange of the path: this step's depth maps to every rank (what the stitcher needs). Issued per step and

@@ -681,3 +681,17 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["world"] == 2 and d["config"]["backend"] == "gloo"
     assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+def test_bench_rccl_calls_at_world_size_one():
+    """The RCCL calls of bench.py's multi-rank flow (process-group init bound to the device, all_gather_into_tensor per step, barrier,
+    all_reduce of the time) on the real backend - at world size 1, all a one-GPU box allows (VDA_BENCH_FORCE_DIST=1): the API usage
+    is exercised, the inter-GPU transport is not."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VDA_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29771", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--encoder", "vits",
+                        "--no-cpu-baseline", "--no-inflight2"], capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["config"]["backend"] == "nccl" and d["config"]["world"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
