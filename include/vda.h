@@ -58,9 +58,13 @@ enum vda_epilogue {
     /* ---- LayerNorm folded into the GEMMs either side of it (block.py:105-106 + :56/:68 of the next sub-block), fp16 path only.
      * The fp32 residual stream x is kept as TWO fp16 planes, x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22+ significant
      * bits): the hi plane IS the A operand of the GEMM that consumes LayerNorm(x), so no LayerNorm pass touches memory. */
-    VDA_EPI_SCALE_RES_SPLIT = 10,/* x' = (res_h + res2_h) + gamma[n]*(acc + bias[n]); out_h = fp16(x'), out2_h = fp16(x' - out_h) (in place
-                                    over res / res2 is allowed); stats[n/64, m, :] = (sum, centred sum of squares) of x' over the 64
-                                    columns n/64*64.. (fp32; N % 64 == 0): vda_ln_stats_finalize turns them into (mean, rstd) rows */
+    VDA_EPI_SCALE_RES_SPLIT = 10,/* x' = (res_h + res2_h) - c[m] + gamma[n]*(acc + bias[n]); out_h = fp16(x'), out2_h = fp16(x' - out_h) (in
+                                    place over res / res2 is allowed); stats[n/64, m, :] = (sum, centred sum of squares) of x' over the 64
+                                    columns n/64*64.. (fp32; N % 64 == 0): vda_ln_stats_finalize turns them into (mean, rstd) rows.
+                                    c[m] = pos[2m] when pos != NULL (the [M, 2] (mean, rstd) rows of the LayerNorm in front of this
+                                    branch: the stream is RE-CENTRED, i.e. kept relative to each token's own mean - every reader of it
+                                    is a LayerNorm, invariant to a per-row shift - so the fp16 operand plane rounds relative to the
+                                    token's spread, not its offset), 0 when pos == NULL (zero_page must then be set) */
     VDA_EPI_LN_BIAS_F16 = 11,    /* A = hi plane, W = W*diag(ln_w) (vda_fold_ln_weight): out_h = rstd[m]*(acc - mean[m]*gamma[n]) + bias[n]
                                     with (mean, rstd) = stats[m, 0:2], gamma = c1 = row sums of the folded W, bias = c2 = b + W.ln_b */
     VDA_EPI_LN_GELU_F16 = 12     /* the same followed by gelu_erf (mlp.fc1) */
@@ -74,7 +78,7 @@ typedef struct vda_gemm_args {
     const void* res;        /* residual (type per epilogue) or NULL */
     const void* res2;       /* second fp16 residual for VDA_EPI_RES_F16 or NULL */
     const float* gamma;     /* [N] LayerScale or NULL */
-    const float* pos;       /* VDA_EPI_PATCH_F32: pos-embed [(P+1), N] */
+    const float* pos;       /* VDA_EPI_PATCH_F32: pos-embed [(P+1), N]; VDA_EPI_SCALE_RES_SPLIT: NULL or re-centring rows [M, 2] */
     const void* zero_page;  /* >= 256 B of zeros (conv padding source) */
     int32_t M, N, K;
     int32_t lda, ldc;       /* in elements */
@@ -90,6 +94,10 @@ typedef struct vda_gemm_args {
     int32_t* sched;         /* NULL, or eight int32 counters ZEROED before the launch (one per XCD): the 8-phase kernel then draws its
                                tiles dynamically - a launch that shares the GPU with another kernel degrades by the CUs it lost,
                                not by a whole shift of tiles. Other kernels ignore it. Results do not depend on it. */
+    int32_t stats_ld;       /* VDA_EPI_SCALE_RES_SPLIT: rows per column block of the stats array (0 = M): lets a caller run a GEMM as
+                               several row ranges (pointers advanced, M = rows of the range) into one [N/64, stats_ld, 2] array */
+    int32_t tile_rows;      /* 0 = the dispatcher's choice; 192 = 192-row tiles where the kernel family has them (the remainder
+                               launch of a row split, vda_gemm_plan_split). Results do not depend on it. */
 } vda_gemm_args;
 
 int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream);
@@ -103,6 +111,15 @@ int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
  * applies; 8 = 192x128 tiles on six waves; 9 = 256x128 8-phase. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
  * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 0, 1). */
 int vda_gemm_set_variant(int v);
+/* Row split of a large dense GEMM on the current device: returns M1 <= M. Rows [0, M1) fill whole rounds of 256 x 256 tiles on the
+ * device's CUs; rows [M1, M) run as one more call with tile_rows = 192 (a 192-row round costs ~0.8 of a 256-row one). M1 == M: no
+ * split pays (or the epilogue / shape has no 192-row kernel). vda_gemm_f16 applies the same plan by itself when sched == NULL and
+ * tile_rows == 0; a caller that wants the two launches bracketed separately (or has per-launch sched counters) splits by hand:
+ * advance A / out / res / res2 / out2 by M1 rows, stats (VDA_EPI_LN_*) and pos (VDA_EPI_SCALE_RES_SPLIT) by M1 rows of 2 floats,
+ * stats (VDA_EPI_SCALE_RES_SPLIT) by M1 rows of 2 floats with stats_ld = M. A row's result is bit-identical either way. */
+int vda_gemm_plan_split(int M, int N, int K, int epilogue, int a_mode);
+/* *out = the arguments of rows [r0, r0 + rows) of *args by exactly those rules (lda / ldc of 0 resolved to K / N first). */
+int vda_gemm_row_range(const vda_gemm_args* args, int r0, int rows, vda_gemm_args* out);
 /* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
 const char* vda_gemm_last_kernel(void);
 
@@ -133,12 +150,15 @@ int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const flo
 /* ---- LayerNorm folded into the neighbouring GEMMs (VDA_EPI_SCALE_RES_SPLIT / VDA_EPI_LN_*; block.py:56,68,105-106)
  * vda_split_stats_f32: fp32 rows x [rows, D] -> the two fp16 planes (hi = fp16(x), lo = fp16(x - hi)) and the row statistics
  *   stat[r] = (mean, rstd = 1/sqrt(var + eps)) (two-pass, fp32): the entry into the split stream after the patch embedding.
+ * vda_split_center_stats_f32: the same with the row's mean taken out first: hi + lo = x - mean(x), stat[r] = (0, rstd) - the entry
+ *   the model uses (the stream then stays relative to each token's mean: VDA_EPI_SCALE_RES_SPLIT's pos).
  * vda_ln_stats_finalize: partial[np, r, 2] (sum, centred sum of squares per 64 columns, as VDA_EPI_SCALE_RES_SPLIT writes them)
  *   -> stat[r] = (mean, rstd), combined in column order (Chan et al.), D = 64*np.
  * vda_layernorm_split_f16: LayerNorm of x = hi + lo (fp32 statistics), fp16 out, group/skip as vda_layernorm_f32_f16 (the taps).
  * vda_fold_ln_weight: pack-time fold of LayerNorm's affine into the Linear that follows it: Wf[n,k] = fp16(W[n,k]*ln_w[k]),
  *   c1[n] = sum_k Wf[n,k] (of the ROUNDED values, fp32), c2[n] = b[n] + sum_k W[n,k]*ln_b[k] (fp32; b may be NULL). */
 int vda_split_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream);
+int vda_split_center_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream);
 int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, vda_stream_t stream);
 int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const float* w, const float* b, float eps,
                             int rows, int D, int group, int skip, vda_stream_t stream);
@@ -159,7 +179,9 @@ int vda_groupnorm_nhwc_f32(const float* in, float* out, const float* w, const fl
 int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream);
 /* fp32-operand twin: qkv fp32 [B, N, 3, heads, 64] -> out fp32 [B, N, heads*64], every product on fp32 MFMA. */
 int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda_stream_t stream);
-/* A-B hook: 1 (default) = V^T fragments via ds_read_b64_tr_b16, scalar softmax math; 2 = packed fp32 softmax math; 0 = scalar LDS
+/* A-B hook: -1 = the default kernel (9); 8 / 9 = the softmax reference point enters through the score MFMAs' C operand (Q pre-scaled
+ * by log2(e)/8), 9 with the lazy rescale (reference point moved only when a score exceeds it by more than 2^6); 1 = the round-2
+ * kernel (V^T fragments via ds_read_b64_tr_b16, scalar softmax math); 2 = packed fp32 softmax math; 0 = scalar LDS
  * reads of V (cross-check); 3 = row sums through the matrix pipe; 4 / 5 = running max through the matrix pipe (without / with 3);
  * 7 = software-pipelined form (next tile's score MFMAs inside the softmax; three waves per SIMD);
  * 10 + k = timing ablations (WRONG results: no exp / max / row sums / PV MFMAs / 1 of 4 QK k-steps), tools/attn_one.py. */

@@ -28,7 +28,13 @@ TOL32 = 1e-3
 # vitl.t32 6.3e-4, vitl.metric_video 4.4e-4, resize_video 2.2e-3, tiny_cls.depth 1.84e-3 - from their first run)
 TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.nonsquare.depth": 1.4e-3, "vits.518.depth_sub": 3.0e-3,
          "vits.518.row_sums": 2.5e-3, "video.relative": 3.6e-3, "video.metric": 4.3e-3, "vitl.2x518": 2.4e-3, "vits.4x518": 7e-4,
-         "vitl.t32": 1.3e-3, "vitl.metric_video": 9e-4, "resize_video": 4.4e-3, "tiny_cls.depth": 3.7e-3}
+         "vitl.t32": 1.3e-3, "vitl.metric_video": 9e-4, "resize_video": 4.4e-3, "tiny_cls.depth": 3.7e-3,
+         # round 3: the BENCHMARKED workloads at their own size (first measured at the commit that added them, bound = 2x)
+         "vits.32x518": 1.0e-3, "vitl.32x518": 2.4e-3,
+         # ... and the outlier-activation state dicts (tests/_outliers.py): see test_outlier_activations
+         # (2x the larger of the two LayerNorm forms, measured: channels 4.0e-3 / 5.1e-3, offset 2.6e-3 / 3.2e-3, both 3.3e-3 / 4.1e-3 for
+         # fold / standalone; the reference's OWN autocast-fp16 path on the same streams: 9.8e-3, 4.3e-2, 8.0e-3)
+         "outlier.channels": 1.0e-2, "outlier.offset": 6.4e-3, "outlier.both": 8.3e-3}
 _measured = {}
 
 
@@ -226,6 +232,116 @@ def test_oracle_metric_vitl_two_windows(fp32):
     d, fps = m.infer_video_depth(frames, 24, input_size=42, device="cuda", fp32=fp32)
     assert d.shape == ref.shape == (40, 42, 56) and fps == 24
     check_map("vitl.metric_video" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.metric_video", fp32))
+
+
+# ---- the BENCHMARKED workloads at their own size (VERDICT r2 missing #1): bench.py's x = randn(1,32,3,518,518) (seed 0) and
+# synthetic_state_dict(seed 0), ViT-S (BASELINE config 2) and ViT-L (config 3, the headline), fp16 AND fp32 operand paths, against
+# ONE oracle run per model (ViT-S ~15 s, ViT-L ~70 s on the box's 16 cores). Covers what no smaller case reaches: the temporal
+# attention at hw = 1369 / 361 / 1369 / 5476 with T = 32, the encoder attention's 192 / 512 (frame, head) problems, every GEMM's
+# partial last round and partial last row tile, 32-bit offsets at the full tensor sizes.
+_full_clip_ref = {}
+
+
+def full_clip_reference(name):
+    if name not in _full_clip_ref:
+        from oracle import vda_oracle as O
+        from video_depth_anything_amd.config import get_config
+        from video_depth_anything_amd.weights import synthetic_state_dict
+        cfg = get_config(name)
+        sd = synthetic_state_dict(cfg, seed=0)
+        x = torch.randn(1, 32, 3, 518, 518, generator=torch.Generator().manual_seed(0))
+        with torch.no_grad():
+            _full_clip_ref[name] = (x, O.forward(sd, cfg, x).numpy())
+    return _full_clip_ref[name]
+
+
+@pytest.mark.parametrize("fp32", PRECISIONS)
+@pytest.mark.parametrize("name", ["vits", "vitl"])
+def test_oracle_full_clip_32x518(name, fp32):
+    x, ref = full_clip_reference(name)
+    m, _, _ = model_for(name, 0)
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    assert d.shape == ref.shape == (1, 32, 518, 518)
+    check_map(f"{name}.32x518.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of(f"{name}.32x518", fp32))
+    # per frame too: one bad frame (a wrong tail round, a temporal-attention wave past the grid) cannot hide in the clip's mean
+    worst = max(rel_l1(d[0, t], ref[0, t]) for t in range(32))
+    record(f"{name}.32x518.worst_frame" + (".f32" if fp32 else ""), worst)
+    assert worst < 2 * tol_of(f"{name}.32x518", fp32)
+    if not fp32:
+        # yardstick (recorded, see autocast_oracle_error): the reference's own autocast-fp16 path against its fp32 result, same clip
+        from video_depth_anything_amd.config import get_config
+        from video_depth_anything_amd.weights import synthetic_state_dict
+        cfg = get_config(name)
+        e_ref16 = autocast_oracle_error(synthetic_state_dict(cfg, seed=0), cfg, x, ref)
+        record(f"{name}.32x518.reference_autocast_fp16", e_ref16)
+        if e_ref16 is not None:
+            assert rel_l1(d, ref) < 1.5 * e_ref16 + 5e-4, "the fp16 path is further from the fp32 reference than the reference's own autocast path"
+
+
+@pytest.mark.parametrize("kind", ["channels", "offset", "both"])
+def test_outlier_activations(kind):
+    """Residual streams shaped like trained DINOv2's (VERDICT r2 missing #2): a few channels hundreds of times the
+    typical magnitude ("channels"), token means tens of standard deviations from zero ("offset"), and both - produced by a
+    seeded state dict with a handful of biases moved (tests/_outliers.py), ViT-S at the vits_forward fixture shape, against the
+    fp32 oracle on the same weights. The fp32 path must hold north_star's 1e-3; the fp16 path is run with the LayerNorm fold on
+    (default) and off and must hold its stated tolerance either way - and the fold may not be more than 2x further from the
+    oracle than the standalone LayerNorm form."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle import vda_oracle as O
+    from _outliers import outlier_state_dict, stream_report
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import VideoDepthAnything
+    cfg = get_config("vits")
+    sd = outlier_state_dict(cfg, seed=21, kind=kind)
+    x = torch.randn(1, 3, 3, 56, 70, generator=torch.Generator().manual_seed(102))
+    with torch.no_grad():
+        ref = O.forward(sd, cfg, x).numpy()
+        rep = stream_report(sd, cfg, x)                  # the oracle's own residual stream: what the state dict really produces
+    for k, v in rep.items():
+        record(f"outlier.{kind}.stream.{k}", v)
+    if kind in ("channels", "both"):
+        assert rep["max_abs"] > 300, rep
+    if kind == "offset":                                 # (with the outlier channels in, they dominate sigma: "both" has |x| ~ 1e3 on top of the shifted stream)
+        assert rep["mean_over_sigma_p50"] > 10, rep
+    m = VideoDepthAnything(encoder="vits", features=cfg.features, out_channels=list(cfg.out_channels))
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    d32 = m.forward(x.cuda(), fp32=True).cpu().numpy()
+    on = m.forward(x.cuda(), fp32=False).cpu().numpy()
+    m.engine.set_option("ln_fold", 0)
+    try:
+        off = m.forward(x.cuda(), fp32=False).cpu().numpy()
+    finally:
+        m.engine.set_option("ln_fold", 1)
+    e_on, e_off = rel_l1(on, ref), rel_l1(off, ref)
+    record(f"outlier.{kind}.ln_fold", e_on)
+    record(f"outlier.{kind}.standalone_ln", e_off)
+    # Yardstick: the REFERENCE's own fp16 path on this stream = the oracle's torch ops on the GPU under torch.autocast (ATen /
+    # rocBLAS / MIOpen: checker only, the product never calls them). How far autocast moves the reference from its fp32 result
+    # is what "fp16 tolerance" can honestly mean here; recorded, and the engine's fp16 path may not be more than 1.5x further.
+    e_ref16 = autocast_oracle_error(sd, cfg, x, ref)
+    record(f"outlier.{kind}.reference_autocast_fp16", e_ref16)
+    check_map(f"outlier.{kind}.f32", d32, ref, TOL32)
+    assert e_on < 2 * e_off + 2e-4, f"LayerNorm fold {e_on:.3e} vs standalone {e_off:.3e} on the '{kind}' stream"
+    if e_ref16 is not None:
+        assert e_on < 1.5 * e_ref16 + 5e-4, f"fp16 path {e_on:.3e} vs the reference's own autocast path {e_ref16:.3e} ('{kind}')"
+    check_map(f"outlier.{kind}.ln_fold", on, ref, TOL16[f"outlier.{kind}"])
+    check_map(f"outlier.{kind}.standalone_ln", off, ref, TOL16[f"outlier.{kind}"])
+
+
+def autocast_oracle_error(sd, cfg, x, ref):
+    """rel-L1 of the oracle run on the GPU under torch.autocast(fp16) - the reference's fp16 path, video_depth.py:203-205 -
+    against its fp32 CPU result `ref`. None if torch's GPU kernels cannot run the shape here."""
+    from oracle import vda_oracle as O
+    try:
+        sdc = {k: v.cuda() for k, v in sd.items()}
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            y = O.forward(sdc, cfg, x.cuda())
+        return rel_l1(y.float().cpu().numpy(), ref)
+    except Exception as e:                                   # noqa: BLE001 - a yardstick, not a requirement
+        print(f"autocast oracle unavailable: {type(e).__name__}: {e}")
+        return None
 
 
 def test_handle_and_python_orchestration_are_bit_identical(golden_dir):
@@ -542,6 +658,14 @@ def test_benchmark_infer_driver(tmp_path):
     assert np.array_equal(got, direct), "the driver must hand the frames as read (BGR) to infer_video_depth(fp32=True) and save its output unchanged"
     swapped, _ = m.infer_video_depth(np.stack([im[:, :, ::-1] for im in imgs]), 1, input_size=70, device="cuda", fp32=True)
     assert not np.array_equal(got, swapped), "channel order must matter for this check to mean anything"
+    # ... and value-correct: the oracle's infer_video_depth (benchmark/infer/infer.py:54-58 hands the BGR frames to
+    # infer_video_depth(..., fp32=True)) on the same frames and weights, at the fp32 path's bar
+    from oracle import vda_oracle as O
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    cfg = get_config("vits")
+    ref, _ = O.infer_video_depth(synthetic_state_dict(cfg, seed=0), cfg, np.stack(imgs), 1, input_size=70)
+    check_map("benchmark_infer.vs_oracle", got, ref, TOL32)
 
 
 # ---------------------------------------------------------------- (c) full sizes through properties
@@ -626,6 +750,22 @@ def test_memory_mapped_video_equals_in_memory_video(tmp_path):
     a, _ = m.infer_video_depth(lazy, fps, input_size=42, device="cuda")
     b, _ = m.infer_video_depth(frames, fps, input_size=42, device="cuda")
     assert a.shape == (70, 42, 56) and np.array_equal(a, b)
+
+
+def test_frames_that_are_not_uint8():
+    """The reference divides whatever array it is handed by 255 (video_depth.py:198); the device path keeps the video as uint8,
+    so integer arrays holding 8-bit values are converted (same arithmetic) and anything else is refused, never truncated."""
+    m, _, _ = model_for("tiny", 6)
+    frames = np.random.default_rng(35).integers(0, 256, (12, 28, 42, 3), dtype=np.uint8)
+    a, _ = m.infer_video_depth(frames, 24, input_size=28, device="cuda")
+    b, _ = m.infer_video_depth(frames.astype(np.int64), 24, input_size=28, device="cuda")
+    assert np.array_equal(a, b)
+    with pytest.raises(TypeError, match="8-bit"):
+        m.infer_video_depth(frames.astype(np.float32) / 255.0, 24, input_size=28, device="cuda")
+    with pytest.raises(TypeError, match="8-bit"):
+        m.infer_video_depth(frames.astype(np.int32) * 2, 24, input_size=28, device="cuda")
+    with pytest.raises(ValueError, match=r"\[N, H, W, 3\]"):
+        m.infer_video_depth(frames[..., 0], 24, input_size=28, device="cuda")
 
 
 def test_1024_frame_vitl_video_properties():

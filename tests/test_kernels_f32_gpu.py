@@ -218,7 +218,7 @@ def test_temporal_attention_f32(ops, Cc, T, hw):
 
 
 # ---------------------------------------------------------------- resampling / layout
-@pytest.mark.parametrize("h,w_,H,W_", [(19, 19, 37, 37), (5, 7, 10, 14), (8, 6, 8, 6), (3, 4, 42, 56)])
+@pytest.mark.parametrize("h,w_,H,W_", [(19, 19, 37, 37), (5, 7, 10, 14), (8, 6, 8, 6), (3, 4, 42, 56), (10, 14, 5, 7), (11, 9, 5, 4), (7, 8, 3, 8)])
 def test_bilinear_nhwc_f32(ops, h, w_, H, W_):
     B, Cc = 2, 64
     x, add = rnd(B, Cc, h, w_, seed=46), rnd(B, H, W_, Cc, seed=47)

@@ -7,10 +7,10 @@ g = torch.Generator(device="cuda").manual_seed(0)
 qkv = torch.randn(32, 1370, 3 * H * 64, device="cuda", generator=g).half()
 o = torch.empty(32, 1370, H * 64, dtype=torch.float16, device="cuda")
 from video_depth_anything_amd import _lib
-for scale in (0.3,):
+for scale in [float(v) for v in os.environ.get('ATTN_SCALES', '0.3,1.0').split(',')]:
     q = (qkv * scale).contiguous()
     for rep in range(int(os.environ.get('ATTN_REPS', '3'))):
-        for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '1,3,4,5').split(',')]:
+        for variant in [int(v) for v in os.environ.get('ATTN_VARIANTS', '1,8,9').split(',')]:
             _lib.lib.vda_attention_set_variant(variant)
             for _ in range(2):
                 ops.attention(q, o, 32, 1370, H)
@@ -21,4 +21,4 @@ for scale in (0.3,):
             e1.record(); torch.cuda.synchronize()
             t = e0.elapsed_time(e1) / 10
             print(f"attention 32x{H}x1370x64 input scale {scale} variant {variant}: {t*1e3:.1f} us  {4.0*32*H*1370*1370*64/t/1e9:.0f} TF/s", flush=True)
-_lib.lib.vda_attention_set_variant(1)
+_lib.lib.vda_attention_set_variant(-1)

@@ -23,6 +23,7 @@ class GemmArgs(C.Structure):
         ("cHo", C.c_int32), ("cWo", C.c_int32), ("cStride", C.c_int32),
         ("P", C.c_int32), ("tK", C.c_int32), ("tH", C.c_int32), ("tW", C.c_int32), ("tCout", C.c_int32),
         ("out2", C.c_void_p), ("stats", C.c_void_p), ("sched", C.c_void_p),
+        ("stats_ld", C.c_int32), ("tile_rows", C.c_int32),
     ]
 
 
@@ -42,11 +43,14 @@ SIGNATURES = {
     "vda_gemm_f16": (_i, [C.POINTER(GemmArgs), _vp]),
     "vda_gemm_f32": (_i, [C.POINTER(GemmArgs), _vp]),
     "vda_gemm_set_variant": (_i, [_i]),
+    "vda_gemm_plan_split": (_i, [_i, _i, _i, _i, _i]),
+    "vda_gemm_row_range": (_i, [C.POINTER(GemmArgs), _i, _i, C.POINTER(GemmArgs)]),
     "vda_gemm_last_kernel": (C.c_char_p, []),
     "vda_layernorm_f32_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_layernorm_residual_f32_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_layernorm_f32_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_split_stats_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
+    "vda_split_center_stats_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "vda_ln_stats_finalize": (_i, [_vp, _vp, _f, _i, _i, _vp]),
     "vda_layernorm_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_fold_ln_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -478,10 +478,186 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3 (variants 8 / 9, the default): the online softmax with the reference point in the MATRIX pipe and a lazy rescale.
+//
+// attn_kernel spends ~185 VALU issues per 64-key tile and wave (32 exp, 31 fma for "score * log2e - max * log2e", 37 adds,
+// 16 max3, 16 cvt_pk, and - on 85 % of the tiles, because SOME query of the wave's 32 sees a new maximum - 32 multiplies of the
+// output accumulators) against 512 cycles of MFMA: it is VALU-bound. Two changes remove ~80 of them:
+//   * Q is pre-scaled by log2(e) / 8 and the score MFMA chains START from a register block holding -m (the query's reference
+//     point, log2 domain; a lane owns ONE query, so the block is the same value in all 16 registers): D = K.Q^T + (-m) comes
+//     out of the matrix pipe ready for v_exp_f32. No fma per score, no extra MFMA (variants 4 / 5 paid two MFMAs per tile for
+//     the same effect and lost).
+//   * The reference point only has to bound the scores, not equal their maximum: it is moved - per lane, by the amount that
+//     lane's maximum exceeds it - only when a score exceeds it by more than LAZY (log2 units), so p <= 2^LAZY (exact in fp16:
+//     the format is floating, fp32 sums). After the first tiles no wave rescales any more; a lane that is not moved multiplies
+//     by exp2(0) = 1 exactly, so a query's result does not depend on its neighbours in the wave.
+// Same tile loop, LDS image, fragment shapes and PV product as attn_kernel.
+template <int LAZY>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) attn_cm_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N,
+                                                                                            int H, int nqb, int total_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = total_blocks >> 3, rm = total_blocks & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int bh = t / nqb, qb = t - bh * nqb;
+    const int b = bh / H, head = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;
+    const unsigned rs32 = (unsigned)rs;
+    const h16* Qb = qkv + (size_t)b * N * rs + head * HD;
+    const h16* Kb = Qb + (size_t)H * HD;
+    const h16* Vb = Kb + (size_t)H * HD;
+
+    // Q fragments, pre-scaled by log2(e) / 8: the scores leave the MFMAs in the log2 domain
+    const int q_row = qb * BQ + wave * 32 + r;
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(qb * BQ + wave * 32 < N)) != 0;
+    h16x8 qf[4];
+    {
+        const h16* qp = Qb + (size_t)min(q_row, N - 1) * rs + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const h16x8*>(qp + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (h16)((float)qf[ks][e] * (0.125f * 1.4426950408889634f));
+        }
+    }
+    const int lrow = lane >> 3, lpos = lane & 7;
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j;
+            const int row = piece * 8 + lrow;
+            const unsigned key = (unsigned)min(kt * BKV + row, N - 1) * rs32;
+            glds16(Kb + (key + ((lpos ^ k_swz(row)) << 3)), buf + piece * 1024);
+            glds16(Vb + (key + ((lpos ^ v_swz(row)) << 3)), buf + TILE_BYTES + piece * 1024);
+        }
+    };
+
+    f32x16 acc_o[2], cneg;                      // cneg: -m in every register = the C operand of each score chain's first MFMA
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc_o[0][e] = 0.f;
+        acc_o[1][e] = 0.f;
+        cneg[e] = 0.f;
+    }
+    float l_run = 0.f;
+    const int nt = (N + BKV - 1) / BKV;
+    stage(0, smem);
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        const char* Kt = smem + cur * STAGE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+        cur ^= 1;
+        if (!wave_active) continue;             // (a wave whose 32 queries lie past N only stages and synchronises)
+
+        // ---- S^T - m = K . Q^T + (-m): two 32-key halves, four 16-channel k-steps each
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int row = sub * 32 + r;
+            const char* kp = Kt + row * 128;
+            const int sw = k_swz(row);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? cneg : s[sub], 0, 0, 0);
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0))) {      // scalar branch, last tile only
+            const int kbase = kt * BKV + 4 * h;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kbase + sub * 32 + (e & 3) + 8 * (e >> 2) >= N) s[sub][e] = -1e30f;
+        }
+        // ---- the tile's maximum per query (lane pair {lane, lane ^ 32}), relative to the reference point
+        float mx = s[0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const bool move = kt == 0 || mx > (float)LAZY;             // first tile: the reference point becomes the tile's maximum
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(move) != 0ull))) {
+            const float delta = move ? mx : 0.f;                    // lanes that stay: alpha = exp2(-0) = 1 exactly, all no-ops
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cneg[e] -= delta;
+        }
+        // ---- p = exp2(s - m) straight from the accumulators, row sums, fp16 fragments of P^T
+        h16x8 pf[4];
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[sub][e]);
+                ps[e & 3] += pv;
+                pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+            }
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+
+        // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
+#pragma unroll
+        for (int kstep = 0; kstep < 4; ++kstep) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h16x8 vf;
+                const int i = lane & 15, qq = i >> 2, pp = i & 3;
+                const int col = c * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int key = kstep * 16 + half * 8 + 4 * h + qq;
+                    const char* ap = Vt + key * 128 + ((((col >> 3) ^ v_swz(key))) << 4) + ((col & 7) << 1);
+                    const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((VDA_LDS_AS fp16x4_t*)ap);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vf[half * 4 + e] = (h16)v4[e];
+                }
+                acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < N) {
+        h16* op = out + ((size_t)b * N + q_row) * ((size_t)H * HD) + head * HD + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o = {(h16)(acc_o[c][4 * g + 0] * inv), (h16)(acc_o[c][4 * g + 1] * inv),
+                           (h16)(acc_o[c][4 * g + 2] * inv), (h16)(acc_o[c][4 * g + 3] * inv)};
+                *reinterpret_cast<h16x4*>(op + c * 32 + 8 * g) = o;
+            }
+    }
+}
+
 }  // namespace
 
-static int g_attn_variant = 1;   // 1: ds_read_b64_tr_b16 V fragments + scalar softmax math (3 % faster than packed, tools/attn_one.py);
-                                 // 2: the same with v_pk_*_f32 softmax math; 0: scalar LDS reads of V (debug cross-check)
+// -1 (default): the kernel picked below. 8 / 9: attn_cm_kernel (reference point through the MFMA C operand; 9 = lazy rescale, 2^6);
+// 1: attn_kernel with ds_read_b64_tr_b16 V fragments + scalar softmax math; 2: the same with v_pk_*_f32 softmax math; 0: scalar LDS
+// reads of V (debug cross-check); 3 / 4 / 5 / 7: the round-2 experiments (row sums / running max through the matrix pipe, the
+// software-pipelined form); 11..15: timing ablations of attn_kernel (wrong results).
+constexpr int VDA_ATTN_DEFAULT = 9;
+static int g_attn_variant = -1;
 
 extern "C" int vda_attention_set_variant(int v) {
     g_attn_variant = v;
@@ -497,13 +673,18 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     VDA_REQUIRE(total < (1ll << 31), "vda_attention_f16: grid too large");
     VDA_REQUIRE((long long)N * 3 * heads * HD < (1ll << 31), "vda_attention_f16: one frame's qkv exceeds 32-bit element offsets");
     hipStream_t s = (hipStream_t)stream;
+    const int g_attn_variant = ::g_attn_variant < 0 ? VDA_ATTN_DEFAULT : ::g_attn_variant;      // (shadows the global inside this call)
 #define VDA_ATTN_ABL(K)                                                                                                                        \
     if (g_attn_variant == 10 + K)                                                                                                              \
         hipLaunchKernelGGL((attn_kernel<true, false, false, false, K>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total); \
     else
     VDA_ATTN_ABL(1) VDA_ATTN_ABL(2) VDA_ATTN_ABL(3) VDA_ATTN_ABL(4) VDA_ATTN_ABL(5)
 #undef VDA_ATTN_ABL
-    if (g_attn_variant == 7)
+    if (g_attn_variant == 8)
+        hipLaunchKernelGGL((attn_cm_kernel<0>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 9)
+        hipLaunchKernelGGL((attn_cm_kernel<6>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 7)
         hipLaunchKernelGGL(attn_pipe_kernel, dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 4)
         hipLaunchKernelGGL((attn_kernel<true, false, false, true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);

@@ -223,6 +223,7 @@ int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm8p_dense_bn256_sched(const vda_gemm_args& a, hipStream_t s, int sched);
 int vda_gemm8p_dense_bn128(const vda_gemm_args& a, hipStream_t s);
+int vda_gemm8p_dense_bn256_bm192(const vda_gemm_args& a, hipStream_t s);         // 192 x 256 tiles; -1 = epilogue not built
 int vda_gemm8p_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 
 // conv_lds.hip: patch-in-LDS direct 3x3 convolution for narrow outputs; -1 when the problem is not one it covers
@@ -266,9 +267,89 @@ extern "C" int vda_gemm_set_variant(int v) {
     return 0;
 }
 
-extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
+static int device_cus() {
+    static thread_local int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0, cu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
+        ncu = cu < 8 ? 8 : (cu & ~7);
+    }
+    return ncu;
+}
+
+static bool bm192_epilogue(int epilogue) {
+    return epilogue == VDA_EPI_BIAS_F16 || epilogue == VDA_EPI_SCALE_RES_F32 || epilogue == VDA_EPI_SCALE_RES_SPLIT || epilogue == VDA_EPI_LN_BIAS_F16;
+}
+
+// Rows [0, M1) on 256 x 256 tiles in whole rounds of the chip, rows [M1, M) on 192 x 256 tiles. Cost model, calibrated on the MI355X
+// (tools/gemm_ab.py -1,5,1029, round 3): a round of 256-row tiles takes t = 1.6 us per K tile + 5 us; a round of 192-row tiles 0.84 t
+// (not 0.75: the load sections of the two-group schedule shrink less than its MFMA sections); the second launch costs ~10 us
+// (boundary, pipeline refill, no cross-launch prefetch). What that leaves: K = 4096 (fc2: 3 rounds -> 2 + 0.84: 315 -> 301 us with the
+// plain epilogue, 357 -> 348 with the split-residual one) pays; K = 1024 (qkv 9 -> 6 + 3 x 0.84: 260 -> 272 us; proj) does not - a
+// partial last round already runs faster than a full one. M1 == M unless the model predicts at least 2.5 % (VDA_GEMM_SPLIT=0: never).
+extern "C" int vda_gemm_plan_split(int M, int N, int K, int epilogue, int a_mode) {
+    static const int allow = getenv("VDA_GEMM_SPLIT") ? atoi(getenv("VDA_GEMM_SPLIT")) : 1;
+    static const int r192 = getenv("VDA_GEMM_R192") ? atoi(getenv("VDA_GEMM_R192")) : 84;
+    if (!allow || a_mode != VDA_A_DENSE || !bm192_epilogue(epilogue) || M < 4096 || N < 256 || K < 256) return M;
+    const long long ncu = device_cus(), nbn = (N + 255) / 256;
+    const long long rt = (M + 255) / 256;
+    auto rounds = [&](long long tiles) { return (tiles + ncu - 1) / ncu; };
+    const double t = 1.6 * (K / 64) + 5.0, launch = allow == 2 ? 0.0 : 10.0;         // us (VDA_GEMM_SPLIT=2: A/B, split whenever rounds say so)
+    const double single = (double)rounds(rt * nbn) * t;
+    double best = single * 0.975;
+    int best_m1 = M;
+    for (long long r = 8; r * 256 < M; ++r) {               // (both parts stay on the 8-phase kernels: >= 2048 rows each, so a row's
+        const long long m2 = M - r * 256;                   // arithmetic - K order, bias in the accumulators' start - is the same in either)
+        if (m2 < 2048) break;
+        const double cost = (double)rounds(r * nbn) * t + 0.01 * r192 * (double)rounds(((m2 + 191) / 192) * nbn) * t + launch;
+        if (cost < best) {
+            best = cost;
+            best_m1 = (int)(r * 256);
+        }
+    }
+    return best_m1;
+}
+
+// args of the row range [r0, r0 + rows) of a dense GEMM (the layout rules of vda_gemm_plan_split's comment in vda.h)
+static vda_gemm_args row_range(const vda_gemm_args& a0, int r0, int rows) {
+    vda_gemm_args a = a0;
+    if (a.lda == 0) a.lda = a.K;
+    if (a.ldc == 0) a.ldc = a.N;
+    vda_gemm_args p = a;
+    auto adv = [&](const void* q, size_t bytes_per_row) -> const void* { return q ? (const char*)q + (size_t)r0 * bytes_per_row : nullptr; };
+    const bool f32_out = a.epilogue == VDA_EPI_SCALE_RES_F32;
+    const size_t ob = f32_out ? 4 : 2;
+    p.A = adv(a.A, (size_t)a.lda * 2);
+    p.out = const_cast<void*>(adv(a.out, (size_t)a.ldc * ob));
+    if (a.epilogue == VDA_EPI_SCALE_RES_F32) p.res = adv(a.res, (size_t)a.ldc * 4);
+    if (a.epilogue == VDA_EPI_SCALE_RES_SPLIT) {
+        p.res = adv(a.res, (size_t)a.ldc * 2);
+        p.res2 = adv(a.res2, (size_t)a.ldc * 2);
+        p.out2 = const_cast<void*>(adv(a.out2, (size_t)a.ldc * 2));
+        p.stats = (float*)const_cast<void*>(adv(a.stats, 8));
+        p.stats_ld = a.stats_ld ? a.stats_ld : a.M;
+        if (a.pos != nullptr && (const void*)a.pos != a.zero_page) p.pos = (const float*)adv(a.pos, 8);
+    }
+    if (a.epilogue == VDA_EPI_LN_BIAS_F16) p.stats = (float*)const_cast<void*>(adv(a.stats, 8));
+    p.M = rows;
+    return p;
+}
+
+extern "C" int vda_gemm_row_range(const vda_gemm_args* args, int r0, int rows, vda_gemm_args* out) {
+    VDA_REQUIRE(args && out && r0 >= 0 && rows > 0 && r0 + rows <= args->M, "vda_gemm_row_range: bad range");
+    VDA_REQUIRE(args->a_mode == VDA_A_DENSE && bm192_epilogue(args->epilogue), "vda_gemm_row_range: dense A and a row-splittable epilogue only");
+    *out = row_range(*args, r0, rows);
+    return 0;
+}
+
+static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, bool may_split);
+
+extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) { return vda_gemm_f16_impl(args, stream, true); }
+
+static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, bool may_split) {
     VDA_REQUIRE(args != nullptr, "vda_gemm_f16: null args");
-    const vda_gemm_args& a = *args;
+    vda_gemm_args a = *args;
     VDA_REQUIRE(a.A && a.W && a.out, "vda_gemm_f16: null operand");
     VDA_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "vda_gemm_f16: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     VDA_REQUIRE(a.K % BK == 0, "vda_gemm_f16: K=%d must be a multiple of %d (pad at pack time)", a.K, BK);
@@ -305,6 +386,15 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             VDA_REQUIRE(a.N % 64 == 0 && a.ldc % 8 == 0 && a.a_mode == VDA_A_DENSE, "vda_gemm_f16: the split-residual epilogue needs a dense A operand, N%%64==0 and ldc%%8==0");
             VDA_REQUIRE(((uintptr_t)a.res & 15) == 0 && ((uintptr_t)a.res2 & 15) == 0 && ((uintptr_t)a.out2 & 15) == 0 && ((uintptr_t)a.stats & 7) == 0,
                         "vda_gemm_f16: split-residual planes must be 16-byte aligned");
+            // re-centring rows (pos = [M, 2] (mean, rstd), optional): the kernels load pos[m * P] unconditionally
+            if (a.pos != nullptr) {
+                VDA_REQUIRE(((uintptr_t)a.pos & 7) == 0, "vda_gemm_f16: pos (re-centring statistics) must be 8-byte aligned");
+                a.P = 2;
+            } else {
+                VDA_REQUIRE(a.zero_page != nullptr, "vda_gemm_f16: the split-residual epilogue without pos needs zero_page");
+                a.pos = (const float*)a.zero_page;
+                a.P = 0;
+            }
             break;
         case VDA_EPI_LN_BIAS_F16:
         case VDA_EPI_LN_GELU_F16:
@@ -376,13 +466,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles
         // (ViT-S proj / fc2: 3 against 2.25; variant 8 forces them). Only the one-barrier 256 x 128 family has the shape.
         bool tall192 = g_gemm_variant == 8 && a.a_mode == VDA_A_DENSE;
-        static thread_local int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0, cu = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
-            ncu = cu < 8 ? 8 : (cu & ~7);
-        }
+        const int ncu = device_cus();
         if (g_gemm_variant < 0 && !eight && big == 128 && a.a_mode == VDA_A_DENSE) {
             const long long nbn = (a.N + 127) / 128;
             const long long r256 = (((a.M + 255) / 256) * nbn + ncu - 1) / ncu, r192 = (((a.M + 191) / 192) * nbn + ncu - 1) / ncu;
@@ -397,6 +481,27 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
             g_last_kernel = a.a_mode == VDA_A_DENSE ? (a.N <= 64 ? "gemm_kernel<128, 64, 0>" : "gemm_kernel<128, 128, 0>")
                                                     : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
             return launch_small(a, s);
+        }
+        // Row split (vda_gemm_plan_split): whole rounds of 256-row tiles + one launch of 192-row tiles for the remainder. Applied here
+        // when the caller left it to the dispatcher (no per-launch sched counters: those belong to ONE launch).
+        if (eight && big == 256 && a.a_mode == VDA_A_DENSE && g_gemm_variant < 0 && may_split && a.tile_rows == 0 && a.sched == nullptr) {
+            const int m1 = vda_gemm_plan_split(a.M, a.N, a.K, a.epilogue, a.a_mode);
+            if (m1 < a.M) {
+                vda_gemm_args p1 = row_range(a, 0, m1), p2 = row_range(a, m1, a.M - m1);
+                p2.tile_rows = 192;
+                const int rc1 = vda_gemm_f16_impl(&p1, stream, false);
+                if (rc1 != 0) return rc1;
+                return vda_gemm_f16_impl(&p2, stream, false);
+            }
+        }
+        if (eight && big == 256 && a.a_mode == VDA_A_DENSE && (a.tile_rows == 192 || g_gemm_variant == 5 + 16 * 64)) {
+            const int rc192 = vda_gemm8p_dense_bn256_bm192(a8, s);
+            if (rc192 >= 0) {
+                static thread_local char name192[64];
+                snprintf(name192, sizeof(name192), "gemm8p_kernel<256, %d, %d, 1, 192>", a.a_mode, a.epilogue);
+                g_last_kernel = name192;
+                return rc192;
+            }
         }
         if (tall192) {
             const int rc192 = vda_gemm256s_dense_bn128_bm192(a8, s);
@@ -414,7 +519,7 @@ extern "C" int vda_gemm_f16(const vda_gemm_args* args, vda_stream_t stream) {
         if (rc >= 0) {
             // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>
             static thread_local char name[64];
-            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d, %d>", big, a.a_mode, a.epilogue, sched8 == 1 ? 0 : sched8 == 2 ? 2 : 1);
+            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d, %d, 256>", big, a.a_mode, a.epilogue, sched8 == 1 ? 0 : sched8 == 2 ? 2 : 1);
             else snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
             g_last_kernel = name;
             return rc;

@@ -28,7 +28,7 @@ namespace vda_gemm8p {
 
 constexpr int BK = 64;
 constexpr int ROW_BYTES = BK * 2;
-constexpr int BM = 256;
+constexpr int BM_MAX = 256;           // the LDS slots are laid out for the 256-row tile (a 192-row tile uses the first 192 rows of each)
 constexpr int NW = 8;                 // waves
 constexpr int NT = NW * 64;
 
@@ -38,15 +38,20 @@ __device__ __forceinline__ void vm_wait_keep() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
 }
 
-template <int BN, int AMODE, int EPI, int SCHED = 1>
+// BM = 192 (BN = 256 only): the same kernel on 192 x 256 tiles (wave tile 96 x 64, three A pieces per wave and K tile, 12 MFMAs per
+// phase). A row's arithmetic is the same in either tile (same K order, same epilogue), so a GEMM may be cut by rows into a part
+// that fills whole rounds of 256-row tiles and a remainder on 192-row tiles whose single round costs ~0.8 of a 256-row round:
+// M = 43 840 leaves 2.69 / 8.06 rounds (proj and fc2 / qkv) that ran as 3 / 9 (vda_gemm_plan_split, gemm.hip).
+template <int BN, int AMODE, int EPI, int SCHED = 1, int BM = 256>
 __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
+    static_assert(BM == 256 || (BM == 192 && BN == 256 && AMODE == VDA_A_DENSE), "192-row tiles: dense A, 256 columns");
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
     constexpr int WM = NW / WN;                    // waves along M
     constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile: 128x64 (BN=256) or 64x64 (BN=128)
     constexpr int MI = WTM / 16, NJ = WTN / 16;    // 16x16 subtiles per wave
     constexpr int MH = MI / 2;                       // subtiles per half of the wave's rows (pipeline unit)
     constexpr int AJ = BM / 8 / NW, WJ = BN / 8 / NW;   // 1-KiB DMA pieces per wave
-    constexpr int A_BYTES = BM * ROW_BYTES, W_BYTES = BN * ROW_BYTES;
+    constexpr int A_BYTES = BM_MAX * ROW_BYTES, W_BYTES = BN * ROW_BYTES;     // (A_BYTES: slot stride)
     static_assert(BN == 256 || BN == 128, "the 8-phase schedule is built for 256 x 256 and 256 x 128 tiles");
     // 256 x 128 (8 waves as 4 x 2, wave tile 64 x 64): the same phases with half the W pieces (1 / 2 / 2 / 1 per phase instead of
     // 2 / 2 / 2 / 2); the counted wait of phase 4 leaves A(kt+2) and the first half of W(kt+2) in flight: AJ + WJ/2 pieces.
@@ -92,7 +97,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     const bool drawer = dyn && wave == 0;                          // wave-uniform
     int fetched = 0;
     volatile VDA_LDS_AS int* const sched_slot =
-        (volatile VDA_LDS_AS int*)(smem + 3 * BM * ROW_BYTES + BN * ROW_BYTES + NW * 1024);      // W slot 1, past the statistics slices
+        (volatile VDA_LDS_AS int*)(smem + 3 * A_BYTES + BN * ROW_BYTES + NW * 1024);      // W slot 1, past the statistics slices
 
     // ---- per-lane DMA sources. A piece is 8 rows x 128 B; lane -> (row lrow of the piece, LDS chunk lane & 7).
     // The swizzled source chunk ((lane&7) ^ ((row>>1)&7)) does not depend on the piece index (pieces are 8 rows
@@ -162,8 +167,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = j0 + jj;
-                const int m = min(tm0 + (wave + NW * j) * 8 + lrow, p.M - 1);
-                glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), abuf + (wave + NW * j) * 1024);
+                if (j < AJ) {                    // (192-row tile: three pieces, issued 2 + 1)
+                    const int m = min(tm0 + (wave + NW * j) * 8 + lrow, p.M - 1);
+                    glds16((const h16*)p.A + (size_t)(unsigned)(m * p.lda + src_chk + k0), abuf + (wave + NW * j) * 1024);
+                }
             }
         } else {
             const int tap = cv_tap, ci0 = cv_ci0;            // set by tap_of(kt) / tap_next(): wave-uniform (scalar registers)
@@ -592,10 +599,11 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
             // partial statistics of the wave tile: [column block][row], rows bm0 + lane and bm0 + 64 + lane: two 512-byte runs
             lgkm0();
-            float* dst = p.stats + ((size_t)(bn0 >> 6) * p.M + bm0) * 2;
+            float* dst = p.stats + ((size_t)(bn0 >> 6) * (p.stats_ld ? p.stats_ld : p.M) + bm0) * 2;
 #pragma unroll
-            for (int hh = 0; hh < WTM / 64; ++hh)
-                if (bm0 + hh * 64 + lane < p.M && bn0 < p.N) *reinterpret_cast<float2*>(dst + (hh * 64 + lane) * 2) = *reinterpret_cast<const float2*>(sst + (hh * 64 + lane) * 8);      // (wave tiles past N hold nothing)
+            for (int hh = 0; hh < (WTM + 63) / 64; ++hh)
+                if (hh * 64 + lane < WTM && bm0 + hh * 64 + lane < p.M && bn0 < p.N)
+                    *reinterpret_cast<float2*>(dst + (hh * 64 + lane) * 2) = *reinterpret_cast<const float2*>(sst + (hh * 64 + lane) * 8);      // (wave tiles past N hold nothing)
         }
         // Every wave is done READING its staging slice before the next tile's K tile 1 lands in it: LDS ordering only, so a raw
         // barrier (a __syncthreads here would also drain the stores and the prefetched K tile 0).
@@ -606,17 +614,17 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     }
 }
 
-template <int BN, int AMODE, int EPI, int SCHED = 1>
+template <int BN, int AMODE, int EPI, int SCHED = 1, int BM = 256>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
-    constexpr int smem = 3 * BM * ROW_BYTES + 2 * BN * ROW_BYTES;
+    constexpr int smem = 3 * BM_MAX * ROW_BYTES + 2 * BN * ROW_BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static VdaKernelDeviceState dev_state;
-    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED>), smem, dev_state);
+    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED, BM>), smem, dev_state);
     if (num_cu < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED>), dim3(grid), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED, BM>), dim3(grid), dim3(NT), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
@@ -638,6 +646,19 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
         case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT>(a, s);
         case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16>(a, s);
         case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16>(a, s);
+        default: break;
+    }
+    return -1;
+}
+
+// 192-row tiles (dense, 256 columns): the epilogues of the encoder GEMMs a row split applies to
+template <int BN>        // (a template only so that the kernels are instantiated in the one translation unit that calls it)
+int launch_dense_bm192(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F16, 1, 192>(a, s);
+        case VDA_EPI_SCALE_RES_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32, 1, 192>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT, 1, 192>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 1, 192>(a, s);
         default: break;
     }
     return -1;

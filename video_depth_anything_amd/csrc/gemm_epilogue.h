@@ -59,11 +59,12 @@ __device__ __forceinline__ void store_one(const vda_gemm_args& p, int m, int n, 
         // (the partial row statistics are written by a separate pass for this layout: see vda_gemm_f16)
         const size_t off = (size_t)m * p.ldc + n;
         const h16x4 rh = *reinterpret_cast<const h16x4*>((const h16*)p.res + off), rl = *reinterpret_cast<const h16x4*>((const h16*)p.res2 + off);
+        const float ctr = p.pos[(size_t)m * p.P];           // re-centring: see load_row_aux
         h16x4 oh, ol;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float g = p.gamma ? p.gamma[n + i] : 1.f;
-            const float x = fmaf(g, v[i], (float)rh[i] + (float)rl[i]);
+            const float x = fmaf(g, v[i], ((float)rh[i] + (float)rl[i]) - ctr);
             h16 a, b;
             split_h16(x, a, b);
             oh[i] = a;
@@ -250,6 +251,12 @@ __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int 
         const size_t off = (size_t)m * p.ldc + n;
         x.h0 = *reinterpret_cast<const h16x8*>((const h16*)p.res + off);
         x.h1 = *reinterpret_cast<const h16x8*>((const h16*)p.res2 + off);
+        // Re-centring of the split stream (vda.h): pos = the (mean, rstd) rows the preceding LayerNorm-folded GEMM consumed; the
+        // row's mean is taken out of the stream as the update goes in, so the planes always hold the token relative to (about)
+        // its own mean and the fp16 rounding of the operand plane is relative to the token's spread, not to its offset. Every
+        // reader of the stream is a LayerNorm (shift-invariant per row). No pos: the dispatcher points it at a zero page with
+        // P = 0 (an unconditional load: a branch around it would make hipcc drain vmcnt per row, cdna_hip_programming.md 5, trap c).
+        x.s0 = p.pos[(size_t)m * p.P];
     } else if constexpr (is_ln_epi<EPI>) {
         const float2 st = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)m);
         x.s0 = st.x;
@@ -277,7 +284,7 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            v[i] = fmaf(c.gamma[i], v[i], (float)x.h0[i] + (float)x.h1[i]);    // hi + lo is exact in fp32
+            v[i] = fmaf(c.gamma[i], v[i], ((float)x.h0[i] + (float)x.h1[i]) - x.s0);    // hi + lo is exact in fp32; s0: re-centring
             h16 a, b;
             split_h16(v[i], a, b);
             oh[i] = a;

@@ -478,7 +478,30 @@ struct Run {
     const void* W(const std::string& k) const { return dry ? nullptr : h->mat[prec].at(k); }
     const float* V(const std::string& k) const { return dry ? nullptr : h->vec.at(k); }
 
+    // A large dense GEMM runs as two launches when that quantises better on this device (vda_gemm_plan_split: whole rounds of
+    // 256-row tiles + the remainder on 192-row tiles). Split HERE rather than inside vda_gemm_f16 so that each launch has its own
+    // dynamic-schedule counters and its own profile bracket (kernel name, FLOPs of its rows).
     int gemm(vda_gemm_args a) {
+        if (prec == VDA_PREC_F16) {
+            const int m1 = vda_gemm_plan_split(a.M, a.N, a.K, a.epilogue, a.a_mode);
+            if (m1 < a.M) {
+                if (dry) {
+                    VDA_TRY(gemm_one(a));
+                    return gemm_one(a);
+                }
+                vda_gemm_args p1, p2;
+                a.zero_page = h->zero_page;
+                VDA_TRY(vda_gemm_row_range(&a, 0, m1, &p1));
+                VDA_TRY(vda_gemm_row_range(&a, m1, a.M - m1, &p2));
+                p1.tile_rows = 256;
+                p2.tile_rows = 192;
+                VDA_TRY(gemm_one(p1));
+                return gemm_one(p2);
+            }
+        }
+        return gemm_one(a);
+    }
+    int gemm_one(vda_gemm_args a) {
         if (prec == VDA_PREC_F16 && h->dyn_sched) {
             if (!dry && sched != nullptr) a.sched = sched + 8 * nsched;
             ++nsched;
@@ -655,7 +678,11 @@ struct Run {
         void* tlo = fold ? buf("tok_lo", (size_t)rows * D, 2) : nullptr;
         float* lnpart = fold ? f32("ln_part", (size_t)rows * (D / 64) * 2) : nullptr;
         float* lnstat = fold ? f32("ln_stat", (size_t)rows * 2) : nullptr;
-        if (fold && !dry) VDA_TRY(vda_split_stats_f32(tok, thi, tlo, lnstat, ENC_LN_EPS, rows, D, s));
+        // The planes hold every token RELATIVE TO ITS OWN MEAN: taken out here, and again by every residual epilogue (a.pos below:
+        // the mean the preceding LayerNorm statistics found), so the operand plane's fp16 rounding is relative to the token's
+        // spread whatever offset the stream carries (tests/_outliers.py "offset": mean / sigma ~ 20 cost 15x the standalone
+        // LayerNorm's error before this). Every reader of the stream is a LayerNorm - invariant to a per-row shift.
+        if (fold && !dry) VDA_TRY(vda_split_center_stats_f32(tok, thi, tlo, lnstat, ENC_LN_EPS, rows, D, s));
         auto ln_gemm = [&](const std::string& wk, void* out, int epi, int N) -> int {         // LayerNorm(x) @ W^T + b on the hi plane
             vda_gemm_args a = {};
             a.A = thi, a.W = W(wk + ".weight.ln"), a.out = out, a.bias = V(wk + ".c2"), a.gamma = V(wk + ".c1"), a.stats = lnstat;
@@ -666,6 +693,7 @@ struct Run {
             vda_gemm_args a = {};
             a.A = A, a.W = W(wk + ".weight"), a.out = thi, a.out2 = tlo, a.res = thi, a.res2 = tlo, a.bias = V(wk + ".bias"), a.gamma = V(gk);
             a.stats = lnpart;
+            a.pos = lnstat;                      // re-centre by the mean the LayerNorm before this branch saw
             a.M = rows, a.N = D, a.K = K, a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_SCALE_RES_SPLIT;
             VDA_TRY(gemm(a));
             if (stats_next && !dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, s));
@@ -956,11 +984,13 @@ static int vda_prepare_impl(vda_model* h, int B, int T, int H, int W, int precis
         void* p = nullptr;
         VDA_TRY(dev_alloc(h, (size_t)(1 + ph * pw) * D * sizeof(float), &p));
         if (ph * pw == POS_GRID * POS_GRID && H == W) {
-            VDA_HIP(hipMemcpy(p, pe, (size_t)(1 + ph * pw) * D * sizeof(float), hipMemcpyDeviceToDevice));     // dinov2.py:183-184
+            // dinov2.py:183-184. A device-to-device hipMemcpy may return before the copy has run, and the first forward reads the
+            // cache on the caller's (non-blocking) stream: complete it here, as the resample branch does
+            VDA_HIP(hipMemcpyAsync(p, pe, (size_t)(1 + ph * pw) * D * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
         } else {
             VDA_TRY(vda_pos_embed_resample_f32(pe, (float*)p, POS_GRID, ph, pw, D, nullptr));
-            VDA_HIP(hipStreamSynchronize(nullptr));
         }
+        VDA_HIP(hipStreamSynchronize(nullptr));
         h->pos_cache[key] = (float*)p;
     }
     Layout* lay = nullptr;

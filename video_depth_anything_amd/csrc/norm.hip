@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256) groupnorm_apply_kernel(const T* __restric
 // The fp32 residual stream of the encoder is kept as two fp16 planes, x = hi + lo (vda.h, VDA_EPI_SCALE_RES_SPLIT).
 //   MODE 0 (vda_split_stats_f32): fp32 rows -> hi, lo planes + stat[row] = (mean, rstd): the entry into the split stream.
 //   MODE 1 (vda_layernorm_split_f16): LayerNorm(hi + lo) * w + b -> fp16, group / skip as layernorm_kernel (the taps).
+//   MODE 2 (vda_split_center_stats_f32): as MODE 0 with the row's mean taken out: hi + lo = x - mean(x), stat[row] = (0, rstd).
 // Same row-in-registers, two-pass fp32 statistics as layernorm_kernel.
 template <int LPR, int NCH, int MODE>
 __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__ xin, const h16* __restrict__ hin, const h16* __restrict__ lin,
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
         if (ok) {
-            if constexpr (MODE == 0) {
+            if constexpr (MODE != 1) {
                 load8(xin + base + ch * 8, v[c]);
             } else {
                 const h16x8 a = *reinterpret_cast<const h16x8*>(hin + base + ch * 8), l = *reinterpret_cast<const h16x8*>(lin + base + ch * 8);
@@ -270,8 +271,10 @@ __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__
     }
     const float rstd = rsqrtf(segment_sum<LPR>(sq, lane) / (float)D + eps);
     if (!row_ok) return;
-    if constexpr (MODE == 0) {
-        if (sub == 0) *reinterpret_cast<float2*>(stat + 2 * (size_t)row) = float2{mean, rstd};
+    if constexpr (MODE != 1) {
+        // MODE 2: the planes hold x - mean (the mean of what they hold is 0 up to fp32 rounding: 1e-7 of the row's spread)
+        const float ctr = MODE == 2 ? mean : 0.f;
+        if (sub == 0) *reinterpret_cast<float2*>(stat + 2 * (size_t)row) = float2{mean - ctr, rstd};
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int ch = sub + c * LPR;
@@ -279,8 +282,9 @@ __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__
                 h16x8 a, l;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    a[e] = (h16)v[c][e];
-                    l[e] = (h16)(v[c][e] - (float)a[e]);
+                    const float d = v[c][e] - ctr;
+                    a[e] = (h16)d;
+                    l[e] = (h16)(d - (float)a[e]);
                 }
                 *reinterpret_cast<h16x8*>(o0 + base + ch * 8) = a;
                 *reinterpret_cast<h16x8*>(o1 + base + ch * 8) = l;
@@ -425,6 +429,13 @@ extern "C" int vda_split_stats_f32(const float* x, void* hi, void* lo, float* st
     VDA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)stat & 7) == 0,
                 "vda_split_stats_f32: 16-byte alignment required");
     return ln_split_launch<0>(x, nullptr, nullptr, (h16*)hi, (h16*)lo, stat, nullptr, nullptr, eps, rows, D, 0, 0, stream);
+}
+
+extern "C" int vda_split_center_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream) {
+    VDA_REQUIRE(x && hi && lo && stat, "vda_split_center_stats_f32: null pointer");
+    VDA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0 && ((uintptr_t)stat & 7) == 0,
+                "vda_split_center_stats_f32: 16-byte alignment required");
+    return ln_split_launch<2>(x, nullptr, nullptr, (h16*)hi, (h16*)lo, stat, nullptr, nullptr, eps, rows, D, 0, 0, stream);
 }
 
 extern "C" int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const float* w, const float* b, float eps, int rows, int D,

@@ -23,7 +23,9 @@ runs on fp32-input MFMA (exact fp32) through the *_f32 entry points; same launch
 
 This Python orchestration is the cross-check of the C++ one behind `vda_forward` (csrc/host.hip), which is what
 `VideoDepthAnything` runs: both issue the same launches on the same layouts, so their outputs are bit-identical
-(tests/test_handle_gpu.py). It also exposes every intermediate stage for the golden tests.
+(tests/test_forward_gpu.py::test_handle_and_python_orchestration_are_bit_identical). It keeps the standalone-LayerNorm form
+(`ln_fold` = 0): the handle's default path (LayerNorm folded into the GEMMs) is cross-checked against the oracle and the goldens
+only - the comparison that matters. It also exposes every intermediate stage for the golden tests.
 
 Algebraic rewrite (exact in real arithmetic): FeatureFusionBlock's `out_conv(bilinear(x))`
 (util/blocks.py:156-160) runs as `bilinear(out_conv(x))`: a 1x1 conv and an align_corners

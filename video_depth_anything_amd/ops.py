@@ -127,10 +127,12 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
         prof.samples.append((name, 2.0 * M * N * K, e0, e1))
 
 
-def split_stats(x, hi, lo, stat, eps, rows, D):
-    """fp32 rows -> the two fp16 planes of the split residual stream (x = hi + lo) and stat[r] = (mean, rstd)."""
+def split_stats(x, hi, lo, stat, eps, rows, D, center=False):
+    """fp32 rows -> the two fp16 planes of the split residual stream (x = hi + lo) and stat[r] = (mean, rstd).
+    center=True: hi + lo = x - mean(x), stat[r] = (0, rstd) (the model's entry: the stream relative to each token's mean)."""
     _req(x, F32, "x"), _req(hi, F16, "hi"), _req(lo, F16, "lo"), _req(stat, F32, "stat")
-    check(lib.vda_split_stats_f32(_p(x), _p(hi), _p(lo), _p(stat), eps, rows, D, _stream(x)), "vda_split_stats_f32")
+    fn = lib.vda_split_center_stats_f32 if center else lib.vda_split_stats_f32
+    check(fn(_p(x), _p(hi), _p(lo), _p(stat), eps, rows, D, _stream(x)), "vda_split_stats_f32")
 
 
 def ln_stats_finalize(partial, stat, eps, rows, np_):

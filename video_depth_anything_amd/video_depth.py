@@ -117,8 +117,17 @@ class VideoDepthAnything:
         from .stitch import stitch_stream
         if not isinstance(frames, np.ndarray):
             frames = np.asarray(frames)
-        if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
-            frames = np.ascontiguousarray(frames).astype(np.uint8)
+        if frames.ndim != 4 or frames.shape[-1] != 3:
+            raise ValueError("infer_video_depth: frames must be [N, H, W, 3], got shape %r" % (tuple(frames.shape),))
+        if frames.dtype != np.uint8:
+            # The reference computes frame.astype(float32) / 255 on whatever it is handed (video_depth.py:198). The device path
+            # keeps the video as uint8 in HBM, which is the same arithmetic exactly when the values ARE 0..255 integers: other
+            # integer dtypes holding such values are converted, anything else (float frames, wider ranges) is refused rather
+            # than silently truncated.
+            if not np.issubdtype(frames.dtype, np.integer) or frames.min() < 0 or frames.max() > 255:
+                raise TypeError("infer_video_depth: frames must hold 8-bit values (uint8, or an integer array within 0..255); got dtype %s"
+                                % frames.dtype)
+            frames = frames.astype(np.uint8)
         H0, W0 = frames.shape[1:3]
         H, W = network_size(H0, W0, input_size)
         dev = eng.device
@@ -204,12 +213,19 @@ class VideoDepthAnything:
 
         def exchange(s):
             """The one exchange of the path (RCCL all-gather over xGMI), issued on the slot's lane behind its window. A rank with
-            no window in this round still takes part, so the slot is acquired here too."""
+            no window in this round still takes part, so the slot is acquired here too.
+            The wait for the collective is bound HERE, explicitly, to the slot's lane (Work.wait() on the NCCL backend is a
+            stream-side wait of whichever stream is current - it does not block the host): computed[s] is recorded behind it, and
+            the consumer's stream waits for that event in ready(s). Nothing depends on which stream happens to be current when
+            drive_windows harvests the round. The lane's next window (two rounds on) queues behind the gather, which by then has
+            long finished under the other lane's compute."""
             acquire(s)
             with torch.cuda.stream(lanes[s]):
                 h = _all_gather(recv[s], send[s])
+                if h is not None:
+                    h.wait()
                 computed[s].record(lanes[s])
-            return h
+            return None
 
         def ready(s):
             compute.wait_event(computed[s])
