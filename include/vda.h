@@ -179,8 +179,9 @@ int vda_groupnorm_nhwc_f32(const float* in, float* out, const float* w, const fl
 int vda_attention_f16(const void* qkv, void* out, int B, int N, int heads, vda_stream_t stream);
 /* fp32-operand twin: qkv fp32 [B, N, 3, heads, 64] -> out fp32 [B, N, heads*64], every product on fp32 MFMA. */
 int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda_stream_t stream);
-/* A-B hook: -1 = the default kernel (9); 8 / 9 = the softmax reference point enters through the score MFMAs' C operand (Q pre-scaled
- * by log2(e)/8), 9 with the lazy rescale (reference point moved only when a score exceeds it by more than 2^6); 1 = the round-2
+/* A-B hook: -1 = the default kernel (10); 8 / 9 / 10 = the softmax reference point enters through the score MFMAs' C operand (Q
+ * pre-scaled by log2(e)/8), 9 with the lazy rescale (reference point moved only when a score exceeds it by more than 2^6), 10 deciding
+ * that from the row sums instead of a running maximum and staging K / V with scalar-offset buffer loads; 1 = the round-2
  * kernel (V^T fragments via ds_read_b64_tr_b16, scalar softmax math); 2 = packed fp32 softmax math; 0 = scalar LDS
  * reads of V (cross-check); 3 = row sums through the matrix pipe; 4 / 5 = running max through the matrix pipe (without / with 3);
  * 7 = software-pipelined form (next tile's score MFMAs inside the softmax; three waves per SIMD);

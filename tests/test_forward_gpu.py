@@ -332,8 +332,12 @@ def test_outlier_activations(kind):
 
 def autocast_oracle_error(sd, cfg, x, ref):
     """rel-L1 of the oracle run on the GPU under torch.autocast(fp16) - the reference's fp16 path, video_depth.py:203-205 -
-    against its fp32 CPU result `ref`. None if torch's GPU kernels cannot run the shape here."""
+    against its fp32 CPU result `ref`. None if torch's GPU kernels cannot run the shape here, or when VDA_TEST_YARDSTICK is not
+    set: MIOpen builds its convolution kernels at first use on a fresh box (minutes), so the yardstick is an opt-in run whose
+    numbers are recorded in DESIGN.md section 2; the default GPU suite does not pay for it."""
     from oracle import vda_oracle as O
+    if os.environ.get("VDA_TEST_YARDSTICK") != "1":
+        return None
     try:
         sdc = {k: v.cuda() for k, v in sd.items()}
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):

@@ -650,13 +650,209 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Variant 10: attn_cm_kernel with two more groups of VALU instructions taken out of the tile loop (PMC on variant 9: VALU issue
+// 82 % of SIMD time, MFMA busy 44 %, 10.8 VALU per MFMA - the loop is bound by VALU ISSUE, not by dependency stalls):
+//   * K / V staging by bounds-checked `buffer_load ... lds` with per-lane constant offsets and ONE scalar per tile (the tile's
+//     row offset in soffset) instead of four 64-bit global addresses per lane and tile (~25 VALU); rows past N are out of the
+//     descriptor's range and arrive as zeros (their scores are masked on the last tile, their V rows meet p = 0).
+//   * no running maximum in the hot path (18 max3 + exchange + compare): whether the reference point must move is read off the
+//     row sum the loop computes anyway - p >= 0, so max p <= sum p, and sum p <= 2^11 proves that no p came near fp16's range.
+//     A wave whose sums say otherwise (spiked scores; always the first tile, whose reference point is 0) takes the slow path:
+//     the scores are formed again from the K tile still in LDS, their maximum moves the reference point exactly as in
+//     attn_cm_kernel, and the tile's p is recomputed. Decided per lane pair (one query): neighbours never change a row's result.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) attn_cs_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
+                                                                                            int nqb, int total_blocks) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qd = total_blocks >> 3, rm = total_blocks & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int bh = t / nqb, qb = t - bh * nqb;
+    const int b = bh / H, head = bh - b * H;
+    const size_t rs = (size_t)3 * H * HD;
+    const unsigned rs32 = (unsigned)rs;
+    const h16* Qb = qkv + (size_t)b * N * rs + head * HD;
+    const h16* Kb = Qb + (size_t)H * HD;
+    const h16* Vb = Kb + (size_t)H * HD;
+
+    const int q_row = qb * BQ + wave * 32 + r;
+    const bool wave_active = __builtin_amdgcn_readfirstlane((int)(qb * BQ + wave * 32 < N)) != 0;
+    h16x8 qf[4];
+    {
+        const h16* qp = Qb + (size_t)min(q_row, N - 1) * rs + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[ks] = *reinterpret_cast<const h16x8*>(qp + ks * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (h16)((float)qf[ks][e] * (0.125f * 1.4426950408889634f));
+        }
+    }
+    // staging: descriptor = the frame's K (V) rows of this head, N rows of 64 halves at stride rs; per-lane byte offsets of the
+    // wave's two pieces (rows piece * 8 + lrow, swizzled 16-byte chunk), constant for the whole kernel
+    const unsigned frame_bytes = ((unsigned)(N - 1) * rs32 + HD) * 2u;            // first byte past row N - 1's 64 halves
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(Kb), 0, frame_bytes, 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(Vb), 0, frame_bytes, 0x00020000);
+    const int lrow = lane >> 3, lpos = lane & 7;
+    unsigned koff[2], voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave + 4 * j) * 8 + lrow;
+        koff[j] = ((unsigned)row * rs32 + (unsigned)((lpos ^ k_swz(row)) << 3)) * 2u;
+        voff[j] = ((unsigned)row * rs32 + (unsigned)((lpos ^ v_swz(row)) << 3)) * 2u;
+    }
+    const unsigned tile_stride = (unsigned)BKV * rs32 * 2u;                         // bytes between key tiles
+    auto stage = [&](int kt, char* buf) {
+        const unsigned so = (unsigned)kt * tile_stride;                             // scalar
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave + 4 * j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (VDA_LDS_AS void*)(buf + piece * 1024), 16, koff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (VDA_LDS_AS void*)(buf + TILE_BYTES + piece * 1024), 16, voff[j], so, 0, 0);
+        }
+    };
+
+    f32x16 acc_o[2], cneg;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        acc_o[0][e] = 0.f;
+        acc_o[1][e] = 0.f;
+        cneg[e] = 0.f;
+    }
+    float l_run = 0.f;
+    constexpr float SUM_LIMIT = 2048.f;             // 2^11: every p of the tile is below it when the row sum is
+    const int nt = (N + BKV - 1) / BKV;
+    stage(0, smem);
+    int cur = 0;
+    for (int kt = 0; kt < nt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        const char* Kt = smem + cur * STAGE_BYTES;
+        const char* Vt = Kt + TILE_BYTES;
+        cur ^= 1;
+        if (!wave_active) continue;
+
+        const bool last_partial = __builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0)) != 0;
+        // scores relative to the reference point: S^T - m = K . Q^T + (-m); keys past N masked
+        auto scores = [&](f32x16 (&s)[2]) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const int row = sub * 32 + r;
+                const char* kp = Kt + row * 128;
+                const int sw = k_swz(row);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((2 * ks + h) ^ sw) << 4));
+                    s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? cneg : s[sub], 0, 0, 0);
+                }
+            }
+            if (last_partial) {
+                const int kbase = kt * BKV + 4 * h;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kbase + sub * 32 + (e & 3) + 8 * (e >> 2) >= N) s[sub][e] = -1e30f;
+            }
+        };
+        // p = exp2(s), fp16 fragments of P^T, the lane's sum over its 32 keys
+        h16x8 pf[4];
+        auto softmax = [&](const f32x16 (&s)[2]) -> float {
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(s[sub][e]);
+                    ps[e & 3] += pv;
+                    pf[sub * 2 + (e >> 3)][e & 7] = (h16)pv;
+                }
+            return (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        };
+        float tsum = 0.f;
+        bool trig = true;                           // first tile: the reference point (0) is not one yet
+        if (kt > 0) {
+            f32x16 s[2];
+            scores(s);
+            tsum = softmax(s);
+            const float qsum = tsum + __shfl_xor(tsum, 32, 64);          // the query's sum over the tile's 64 keys
+            trig = !(qsum <= SUM_LIMIT);                                  // (also true for inf / nan)
+        }
+        if (__builtin_amdgcn_readfirstlane((int)(__ballot(trig) != 0ull))) {
+            // slow path: scores again (the K tile is still in LDS), their maximum moves the reference point of the lanes that asked
+            f32x16 s[2];
+            scores(s);
+            float mx = s[0][0];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[sub][e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float delta = trig ? mx : 0.f;                          // lanes that stay: exp2(-0) = 1 exactly, all no-ops
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            l_run *= alpha;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[c][e] *= alpha;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[sub][e] -= delta;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cneg[e] -= delta;
+            tsum = softmax(s);
+        }
+        l_run += tsum;
+
+        // ---- O^T += V^T . P^T  (4 steps of 16 keys, 2 halves of 32 channels)
+#pragma unroll
+        for (int kstep = 0; kstep < 4; ++kstep) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                h16x8 vf;
+                const int i = lane & 15, qq = i >> 2, pp = i & 3;
+                const int col = c * 32 + 16 * ((lane >> 4) & 1) + 4 * pp;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int key = kstep * 16 + half * 8 + 4 * h + qq;
+                    const char* ap = Vt + key * 128 + ((((col >> 3) ^ v_swz(key))) << 4) + ((col & 7) << 1);
+                    const fp16x4_t v4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((VDA_LDS_AS fp16x4_t*)ap);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vf[half * 4 + e] = (h16)v4[e];
+                }
+                acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < N) {
+        h16* op = out + ((size_t)b * N + q_row) * ((size_t)H * HD) + head * HD + 4 * h;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16x4 o = {(h16)(acc_o[c][4 * g + 0] * inv), (h16)(acc_o[c][4 * g + 1] * inv),
+                           (h16)(acc_o[c][4 * g + 2] * inv), (h16)(acc_o[c][4 * g + 3] * inv)};
+                *reinterpret_cast<h16x4*>(op + c * 32 + 8 * g) = o;
+            }
+    }
+}
+
 }  // namespace
 
-// -1 (default): the kernel picked below. 8 / 9: attn_cm_kernel (reference point through the MFMA C operand; 9 = lazy rescale, 2^6);
+// -1 (default): the kernel picked below. 10: attn_cs_kernel (as 9, staging by scalar-offset buffer loads, no maximum in the hot path);
+// 8 / 9: attn_cm_kernel (reference point through the MFMA C operand; 9 = lazy rescale, 2^6);
 // 1: attn_kernel with ds_read_b64_tr_b16 V fragments + scalar softmax math; 2: the same with v_pk_*_f32 softmax math; 0: scalar LDS
 // reads of V (debug cross-check); 3 / 4 / 5 / 7: the round-2 experiments (row sums / running max through the matrix pipe, the
 // software-pipelined form); 11..15: timing ablations of attn_kernel (wrong results).
-constexpr int VDA_ATTN_DEFAULT = 9;
+constexpr int VDA_ATTN_DEFAULT = 10;
 static int g_attn_variant = -1;
 
 extern "C" int vda_attention_set_variant(int v) {
@@ -680,7 +876,9 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     else
     VDA_ATTN_ABL(1) VDA_ATTN_ABL(2) VDA_ATTN_ABL(3) VDA_ATTN_ABL(4) VDA_ATTN_ABL(5)
 #undef VDA_ATTN_ABL
-    if (g_attn_variant == 8)
+    if (g_attn_variant == 10)
+        hipLaunchKernelGGL(attn_cs_kernel, dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 8)
         hipLaunchKernelGGL((attn_cm_kernel<0>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 9)
         hipLaunchKernelGGL((attn_cm_kernel<6>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);

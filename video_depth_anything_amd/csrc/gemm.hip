@@ -287,17 +287,18 @@ static bool bm192_epilogue(int epilogue) {
 // (not 0.75: the load sections of the two-group schedule shrink less than its MFMA sections); the second launch costs ~10 us
 // (boundary, pipeline refill, no cross-launch prefetch). What that leaves: K = 4096 (fc2: 3 rounds -> 2 + 0.84: 315 -> 301 us with the
 // plain epilogue, 357 -> 348 with the split-residual one) pays; K = 1024 (qkv 9 -> 6 + 3 x 0.84: 260 -> 272 us; proj) does not - a
-// partial last round already runs faster than a full one. M1 == M unless the model predicts at least 2.5 % (VDA_GEMM_SPLIT=0: never).
+// partial last round already runs faster than a full one, which a round count cannot see: K < 2048 never splits. M1 == M unless
+// the model predicts at least 1.5 % (VDA_GEMM_SPLIT=0: never; 2: whenever the round count says so, any K - the A/B switch).
 extern "C" int vda_gemm_plan_split(int M, int N, int K, int epilogue, int a_mode) {
     static const int allow = getenv("VDA_GEMM_SPLIT") ? atoi(getenv("VDA_GEMM_SPLIT")) : 1;
     static const int r192 = getenv("VDA_GEMM_R192") ? atoi(getenv("VDA_GEMM_R192")) : 84;
-    if (!allow || a_mode != VDA_A_DENSE || !bm192_epilogue(epilogue) || M < 4096 || N < 256 || K < 256) return M;
+    if (!allow || a_mode != VDA_A_DENSE || !bm192_epilogue(epilogue) || M < 4096 || N < 256 || K < (allow == 2 ? 256 : 2048)) return M;
     const long long ncu = device_cus(), nbn = (N + 255) / 256;
     const long long rt = (M + 255) / 256;
     auto rounds = [&](long long tiles) { return (tiles + ncu - 1) / ncu; };
     const double t = 1.6 * (K / 64) + 5.0, launch = allow == 2 ? 0.0 : 10.0;         // us (VDA_GEMM_SPLIT=2: A/B, split whenever rounds say so)
     const double single = (double)rounds(rt * nbn) * t;
-    double best = single * 0.975;
+    double best = single * 0.985;
     int best_m1 = M;
     for (long long r = 8; r * 256 < M; ++r) {               // (both parts stay on the 8-phase kernels: >= 2048 rows each, so a row's
         const long long m2 = M - r * 256;                   // arithmetic - K order, bias in the accumulators' start - is the same in either)
