@@ -265,6 +265,9 @@ int vda_lsq_scale_shift_f32(const float* pred, const float* target, long long n,
  * chunk: fp32 [22, px]; tail: fp32 [8, px] updated in place; scale_shift, wts: device fp32 [2], [16]. */
 int vda_stitch_window_f32(const float* win, const float* scale_shift, float* chunk, float* tail, float* ref1, long long px,
                           const float* wts, vda_stream_t stream);
+/* out[i] = aff(in[i]) for n elements, the same arithmetic as the stitch (video_depth.py:238,243,249): aligns key frames another rank
+ * computed (the key-frame exchange of the multi-rank schedule). in == out is allowed. */
+int vda_affine_clamp_f32(const float* in, const float* scale_shift, float* out, long long n, vda_stream_t stream);
 
 /* ================================================================ handle API: the model behind one pointer
  * What a C / C++ host binds in place of the reference's Python class (the seam of SURVEY.md section 8b):

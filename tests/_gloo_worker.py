@@ -15,6 +15,7 @@ from video_depth_anything_amd.weights import synthetic_state_dict  # noqa: E402
 
 def main():
     out, n_frames = sys.argv[1], int(sys.argv[2])
+    exchange = sys.argv[3] if len(sys.argv) > 3 else "windows"
     torch.set_num_threads(2)
     cfg = get_config("tiny")
     sd = synthetic_state_dict(cfg, seed=5)
@@ -29,10 +30,13 @@ def main():
 
     dist.init_process_group("gloo")
     rank = dist.get_rank()
-    d = S.run_windows(frames, window_fn)
+    d = S.run_windows(frames, window_fn, exchange=exchange)
     nwin = len(S.plan_windows(n_frames))
     assert len(calls) == len(S.shard_windows(nwin, dist.get_world_size(), rank)), "each rank computes only its own windows"
     np.save(f"{out}_rank{rank}.npy", d)
+    if exchange == "keys":                        # only rank 1 wants the video: the others deliver their pieces and return None
+        d1 = S.run_windows(frames, window_fn, exchange="keys", result_ranks=(1,))
+        assert (d1 is None) == (rank != 1) and (rank != 1 or np.array_equal(d1, d))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

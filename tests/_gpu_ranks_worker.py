@@ -30,6 +30,15 @@ def main():
     kinds = [None] * world
     dist.all_gather_object(kinds, f"rank{rank}:{'None' if d0 is None else 'array'}")
     m.result_ranks = None
+    # the key-frame exchange (scheduler.drive_windows_keys on the device): bit-equal, every rank / only rank 2 receiving
+    m.exchange = "keys"
+    dk, _ = m.infer_video_depth(frames, 24, input_size=28)
+    assert np.array_equal(dk, d), f"rank {rank}: key-frame exchange differs from the window exchange"
+    m.result_ranks = (2,)
+    d2, _ = m.infer_video_depth(frames, 24, input_size=28)
+    assert ((d2 is None) != (rank == 2)) and (rank != 2 or np.array_equal(d2, d))
+    m.result_ranks = None
+    m.exchange = "windows"
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:

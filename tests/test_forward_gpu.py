@@ -90,6 +90,15 @@ def nhwc_to_nchw(t, B, h, w, Cp, C):
 
 PRECISIONS = [pytest.param(False, id="fp16"), pytest.param(True, id="fp32")]
 
+_oracle_memo = {}
+
+
+def oracle_once(key, fn):
+    """The CPU oracle's result for a (model, input) pair, computed once for the fp16 and fp32 parametrisations of a test."""
+    if key not in _oracle_memo:
+        _oracle_memo[key] = fn()
+    return _oracle_memo[key]
+
 
 def tol_of(key, fp32):
     return TOL32 if fp32 else TOL16[key]
@@ -183,7 +192,7 @@ def test_oracle_vits_4frames_518(fp32):
     m, cfg, sd = model_for("vits", 7)
     x = torch.randn(1, 4, 3, 518, 518, generator=torch.Generator().manual_seed(70))
     with torch.no_grad():
-        ref = O.forward(sd, cfg, x).numpy()
+        ref = oracle_once("vits.4x518", lambda: O.forward(sd, cfg, x).numpy())
     d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
     check_map("vits.4x518.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vits.4x518", fp32))
 
@@ -195,7 +204,7 @@ def test_oracle_vitl_2frames_518(fp32):
     m, cfg, sd = model_for("vitl", 3)
     x = torch.randn(1, 2, 3, 518, 518, generator=torch.Generator().manual_seed(72))
     with torch.no_grad():
-        ref = O.forward(sd, cfg, x).numpy()
+        ref = oracle_once("vitl.2x518", lambda: O.forward(sd, cfg, x).numpy())
     d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
     check_map("vitl.2x518.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.2x518", fp32))
 
@@ -208,7 +217,7 @@ def test_oracle_vitl_32frames_small(fp32):
     m, cfg, sd = model_for("vitl", 4)
     x = torch.randn(1, 32, 3, 70, 84, generator=torch.Generator().manual_seed(73))
     with torch.no_grad():
-        ref = O.forward(sd, cfg, x).numpy()
+        ref = oracle_once("vitl.32x70x84", lambda: O.forward(sd, cfg, x).numpy())
     d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
     check_map("vitl.32x70x84.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.t32", fp32))
 
@@ -228,7 +237,7 @@ def test_oracle_metric_vitl_two_windows(fp32):
     m.load_state_dict(sd, strict=True)
     m = m.to("cuda").eval()
     frames = np.random.default_rng(31).integers(0, 256, (40, 42, 56, 3), dtype=np.uint8)
-    ref, _ = O.infer_video_depth(sd, cfg, frames, 24, input_size=42, metric=True)
+    ref = oracle_once("vitl.metric_video", lambda: O.infer_video_depth(sd, cfg, frames, 24, input_size=42, metric=True)[0])
     d, fps = m.infer_video_depth(frames, 24, input_size=42, device="cuda", fp32=fp32)
     assert d.shape == ref.shape == (40, 42, 56) and fps == 24
     check_map("vitl.metric_video" + (".f32" if fp32 else ""), d, ref, tol_of("vitl.metric_video", fp32))
@@ -740,6 +749,24 @@ def test_long_video_equals_per_window_forward_plus_host_stitcher():
     # the lanes would show as run-to-run differences
     d2, _ = m.infer_video_depth(frames, 24, input_size=518, device="cuda", fp32=False)
     assert np.array_equal(d, d2), "infer_video_depth must be bitwise reproducible"
+
+
+def test_key_frame_exchange_equals_window_exchange_single_rank():
+    """model.exchange = "keys" (key frames gathered, scale/shift chain everywhere, every rank finalises its own
+    windows) on one rank: the same kernels in the same order as the window exchange + device stitcher - bit-equal, relative and
+    metric, several window counts."""
+    from video_depth_anything_amd.video_depth import MetricVideoDepthAnything, VideoDepthAnything
+    for cls in (VideoDepthAnything, MetricVideoDepthAnything):
+        m, _, _ = model_for("tiny", 6, cls)
+        for n in (9, 40, 77):
+            frames = np.random.default_rng(40 + n).integers(0, 256, (n, 42, 56, 3), dtype=np.uint8)
+            a, _ = m.infer_video_depth(frames, 24, input_size=42, device="cuda")
+            m.exchange = "keys"
+            try:
+                b, _ = m.infer_video_depth(frames, 24, input_size=42, device="cuda")
+            finally:
+                m.exchange = "windows"
+            assert a.shape == b.shape == (n, 42, 56) and np.array_equal(a, b), (cls.__name__, n)
 
 
 def test_memory_mapped_video_equals_in_memory_video(tmp_path):

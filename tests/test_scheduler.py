@@ -114,13 +114,18 @@ def test_run_windows_single_rank_reproduces_reference_video(golden_dir):
     assert err < 5e-5
 
 
+@pytest.mark.parametrize("exchange", ["windows", "keys"])
 @pytest.mark.parametrize("world,n_frames", [(2, 60), (3, 100)], ids=["2ranks_3windows", "3ranks_5windows"])
-def test_ranks_over_gloo_equal_one_rank(tmp_path, world, n_frames):
+def test_ranks_over_gloo_equal_one_rank(tmp_path, world, n_frames, exchange):
     """gloo, world size 2 and 3 (uneven shards: 2+1 and 2+2+1 windows): the round-robin schedule of drive_windows - the one the
-    device path runs - with its per-round all-gather and two-slot rings == the single-process result, on every rank."""
+    device path runs - with its per-round all-gather and two-slot rings == the single-process result, on every rank.
+    exchange="keys": the key-frame schedule of SURVEY.md section 8(e) (drive_windows_keys: 11 key frames per window all-gathered, the
+    scale/shift chain on every rank, each rank finalises its own windows, pieces delivered to the result ranks): bit-equal too,
+    with every rank or only rank 1 as the receiver."""
     out = tmp_path / "r"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29731 + world), os.path.join(REPO, "tests", "_gloo_worker.py"), str(out), str(n_frames)]
+           "--master-port", str(29731 + world + (10 if exchange == "keys" else 0)), os.path.join(REPO, "tests", "_gloo_worker.py"), str(out), str(n_frames),
+           exchange]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -128,6 +133,23 @@ def test_ranks_over_gloo_equal_one_rank(tmp_path, world, n_frames):
     assert ref.shape == (n_frames, 28, 42)
     for rank in range(world):
         np.testing.assert_array_equal(np.load(f"{out}_rank{rank}.npy"), ref)
+
+
+def test_key_schedule_equals_window_schedule_single_rank():
+    """drive_windows_keys against drive_windows + stitch_windows on one rank: bit-equal for every window count / remainder, both
+    stitch modes; every output frame is delivered exactly once (asserted inside run_windows)."""
+    rng = np.random.default_rng(3)
+    for n in (1, 20, 32, 33, 54, 55, 76, 131):
+        frames = rng.integers(0, 256, (n, 6, 8, 3), dtype=np.uint8)
+
+        def window_fn(w):
+            x = w.astype(np.float32).mean(-1)
+            return (x * (1 + 0.001 * x.mean()) + 3).astype(np.float32)
+
+        for metric in (False, True):
+            a = S.run_windows(frames, window_fn, metric=metric)
+            b = S.run_windows(frames, window_fn, metric=metric, exchange="keys")
+            assert np.array_equal(a, b), (n, metric)
 
 
 def test_round_robin_shards_cover_every_window_once():

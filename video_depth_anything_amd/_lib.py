@@ -79,6 +79,7 @@ SIGNATURES = {
     "vda_gather_resize_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_lsq_scale_shift_f32": (_i, [_vp, _vp, C.c_longlong, _vp, _i, _vp, _vp]),
     "vda_stitch_window_f32": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_longlong, _vp, _vp]),
+    "vda_affine_clamp_f32": (_i, [_vp, _vp, _vp, C.c_longlong, _vp]),
     # handle API
     "vda_create": (_i, [C.POINTER(Config), C.POINTER(_vp)]),
     "vda_destroy": (_i, [_vp]),

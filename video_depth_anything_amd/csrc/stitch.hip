@@ -99,7 +99,23 @@ __global__ void __launch_bounds__(256) stitch_window_kernel(const float* __restr
     for (int j = 0; j < 8; ++j) tail[j * px + i] = affine_clamp(win[(24 + j) * px + i], sc, sh);
 }
 
+// out[i] = aff(in[i]): the aligned form of key frames other ranks computed (the key-frame exchange, scheduler.drive_windows_keys);
+// the same affine_clamp as stitch_window_kernel, so a frame aligned here is bit-equal to the one its owner's stitch produces
+__global__ void __launch_bounds__(256) affine_clamp_kernel(const float* __restrict__ in, const float* __restrict__ scale_shift, float* __restrict__ out,
+                                                           long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = affine_clamp(in[i], scale_shift[0], scale_shift[1]);
+}
+
 }  // namespace
+
+extern "C" int vda_affine_clamp_f32(const float* in, const float* scale_shift, float* out, long long n, vda_stream_t stream) {
+    VDA_REQUIRE(in && scale_shift && out, "vda_affine_clamp_f32: null pointer");
+    VDA_REQUIRE(n > 0 && n < (1ll << 31) * 256, "vda_affine_clamp_f32: bad size %lld", n);
+    hipLaunchKernelGGL(affine_clamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, scale_shift, out, n);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int vda_lsq_scale_shift_f32(const float* pred, const float* target, long long n, double* workspace, int nblk, float* scale_shift,
                                        vda_stream_t stream) {

@@ -290,6 +290,14 @@ def stitch_window(win, scale_shift, chunk, tail, ref1, px, wts):
     check(lib.vda_stitch_window_f32(_p(win), _p(scale_shift), _p(chunk), _p(tail), _p(ref1), px, _p(wts), _stream(win)), "vda_stitch_window_f32")
 
 
+def affine_clamp(x, scale_shift, out):
+    """out = max(x * scale + shift, 0) elementwise (the stitch's alignment of a frame), device scale_shift[2]."""
+    _req(x, F32, "x"), _req(scale_shift, F32, "scale_shift"), _req(out, F32, "out")
+    if out.numel() < x.numel() or scale_shift.numel() < 2:
+        raise ValueError("affine_clamp buffers too small")
+    check(lib.vda_affine_clamp_f32(_p(x), _p(scale_shift), _p(out), x.numel(), _stream(x)), "vda_affine_clamp_f32")
+
+
 # ---------------------------------------------------------------------------
 # Weight layouts the kernels expect (done once at load time, on the host or device)
 # ---------------------------------------------------------------------------

@@ -119,6 +119,150 @@ def drive_windows(n_windows: int, world: int, rank: int, send, recv, compute, ga
     yield from harvest(pending)
 
 
+# ------------------------------------------------------------------ the exchange that moves only what the stitch chain needs
+# SURVEY.md section 8(e), "optional refinement": the only dependence BETWEEN windows in video_depth.py:216-250 is the chain
+#   (scale_k, shift_k) = lsq(window k slots [0, 1]  ->  [window 0 slot 0, aligned window k-1 slot 12])
+# plus the 8-frame cross-fade of window k's slots 2..9 into window k-1's aligned slots 24..31. So instead of all-gathering whole
+# windows (32 frames per rank and round) the ranks all-gather 11 KEY frames per window - slots 0, 1 (the alignment pair), 12 (the
+# next reference) and 24..31 (the tail the next window's owner cross-fades into) -, every rank runs the scale/shift chain on them,
+# and each rank FINALISES ITS OWN windows: window k > 0 yields the 22 output frames 22k+2 .. 22k+23, window 0 the frames 0..23,
+# the last window also its tail. Only those final pieces travel to the ranks that want the video.
+# Per round and rank: 11 frames all-gathered + 22..24 sent to each result rank, against 32 all-gathered; a rank that is not a
+# result rank receives 7 x 11 instead of 7 x 32 frames on 8 GPUs, and the stitch work is spread over the ranks.
+KEY_SLOTS = (0, 1, 12, 24, 25, 26, 27, 28, 29, 30, 31)
+PIECE_FRAMES = INFER_LEN - INTERP_LEN            # 24: the largest piece (window 0); later windows fill 22 of it
+
+
+def piece_position(k: int) -> Tuple[int, int]:
+    """(first output frame, frame count) of the piece window k's owner finalises."""
+    return (0, PIECE_FRAMES) if k == 0 else ((INFER_LEN - OVERLAP) * k + (OVERLAP - INTERP_LEN), INFER_LEN - OVERLAP)
+
+
+def drive_windows_keys(n_windows: int, world: int, rank: int, ops, result_ranks=None):
+    """The key-frame schedule (device path and CPU rehearsal alike): yields (first output frame, count, frames[count..]) pieces,
+    every piece of the video exactly once, on the ranks in `result_ranks` (None = every rank); nothing elsewhere.
+
+    ops.compute(k, s)          window k into slot s of a two-slot ring, its KEY_SLOTS frames into the slot's key buffer
+    ops.gather_keys(s)         start the all-gather of the slot's key buffers; returns a handle with .wait() or None
+    ops.chain(k, s, r)         advance the scale/shift chain by window k, whose key frames are rank r's entry of slot s's gather
+                               (called on every rank for every window, in window order)
+    ops.finalise(k, s)         this rank's window k (still in slot s) -> its final piece, in the slot's piece buffer
+    ops.deliver(s, j)          collective: the pieces of round j's windows to the result ranks; returns [(k, frames)] there, [] elsewhere
+    ops.last_tail(k, owner)    the last window's aligned tail (8 frames): the chain holds it on every rank (its key frames are slots 24..31)
+    Round j's key gather runs under round j + 1's compute; the chain, the finalisation and the delivery of a round happen one
+    round behind, exactly as drive_windows harvests."""
+    mine = lambda k: k % world == rank                     # noqa: E731 - round-robin shards (shard_windows)
+    wanted = result_ranks is None or rank in result_ranks
+    pending = None
+
+    def harvest(p):
+        j, s, h = p
+        if h is not None:
+            h.wait()
+        for r in range(world):
+            k = j * world + r
+            if k < n_windows:
+                ops.chain(k, s, r)
+        k = j * world + rank
+        if k < n_windows:
+            ops.finalise(k, s)
+        for k2, frames in ops.deliver(s, j):
+            pos, cnt = piece_position(k2)
+            yield pos, cnt, frames
+
+    nround = rounds(n_windows, world)
+    for j in range(nround):
+        s = j % 2
+        k = j * world + rank
+        if k < n_windows:
+            ops.compute(k, s)
+        h = ops.gather_keys(s)
+        if pending is not None:
+            yield from harvest(pending)
+        pending = (j, s, h)
+    yield from harvest(pending)
+    last = n_windows - 1
+    tail = ops.last_tail(last, last % world)
+    if wanted and tail is not None:
+        yield (INFER_LEN - OVERLAP) * last + PIECE_FRAMES, INTERP_LEN, tail
+
+
+class HostKeyOps:
+    """drive_windows_keys on the host: numpy arithmetic identical to stitch_windows (so the result is bit-equal to the single-rank
+    stitch), torch.distributed (gloo) on CPU tensors for the exchanges. The CPU tests' stand-in for the device ops."""
+
+    def __init__(self, frames, plan, window_fn, metric, world, rank, result_ranks, group=None):
+        import torch
+        self.torch, self.frames, self.plan, self.window_fn, self.metric = torch, frames, plan, window_fn, metric
+        self.world, self.rank, self.result_ranks, self.group = world, rank, result_ranks, group
+        H0, W0 = frames.shape[1:3]
+        self.win = [None, None]
+        self.keys_send = [torch.zeros(len(KEY_SLOTS), H0, W0) for _ in range(2)]
+        self.keys_recv = [torch.zeros(world, len(KEY_SLOTS), H0, W0) for _ in range(2)]
+        self.piece = [torch.zeros(PIECE_FRAMES, H0, W0) for _ in range(2)]
+        self.anchor = self.ref1 = None
+        self.scale, self.shift = 1.0, 0.0
+        self.tail = None                    # aligned slots 24..31 of the window the chain saw last
+        self.my = {}                        # window -> (scale, shift, previous window's aligned tail) for the windows this rank owns
+        self.last_tail_frames = None
+
+    def compute(self, k, s):
+        w = np.ascontiguousarray(self.window_fn(self.frames[self.plan[k]]), dtype=np.float32)
+        self.win[s] = w
+        self.keys_send[s].copy_(self.torch.from_numpy(w[list(KEY_SLOTS)]))
+
+    def gather_keys(self, s):
+        import torch.distributed as dist
+        if self.world == 1:
+            self.keys_recv[s][0].copy_(self.keys_send[s])
+            return None
+        n = len(KEY_SLOTS)
+        return dist.all_gather_into_tensor(self.keys_recv[s].view(self.world * n, *self.keys_send[s].shape[1:]), self.keys_send[s],
+                                           group=self.group, async_op=True)
+
+    def chain(self, k, s, r):
+        keys = self.keys_recv[s][r].numpy()
+        prev_tail = self.tail
+        if k == 0:
+            self.anchor, self.ref1 = keys[0].copy(), keys[2].copy()
+            self.scale, self.shift = 1.0, 0.0
+            self.tail = [keys[3 + i].copy() for i in range(INTERP_LEN)]
+        else:
+            if not self.metric:
+                self.scale, self.shift = compute_scale_and_shift(np.concatenate([keys[0], keys[1]]), np.concatenate([self.anchor, self.ref1]))
+            self.ref1 = _clamped_affine(keys[2], self.scale, self.shift)
+            self.tail = [_clamped_affine(keys[3 + i], self.scale, self.shift) for i in range(INTERP_LEN)]
+        if k % self.world == self.rank:
+            self.my[k] = (self.scale, self.shift, prev_tail)
+
+    def finalise(self, k, s):
+        w = self.win[s]
+        scale, shift, prev_tail = self.my.pop(k)
+        if k == 0:
+            out = [w[i] for i in range(PIECE_FRAMES)]
+        else:
+            post = [_clamped_affine(w[i], scale, shift) for i in range(OVERLAP - INTERP_LEN, OVERLAP)]
+            out = crossfade(prev_tail, post) + [_clamped_affine(w[i], scale, shift) for i in range(OVERLAP, INFER_LEN - INTERP_LEN)]
+        self.piece[s][:len(out)].copy_(self.torch.from_numpy(np.stack(out)))
+
+    def deliver(self, s, j):
+        import torch.distributed as dist
+        ks = [j * self.world + r for r in range(self.world)]
+        if self.world == 1:
+            return [(ks[0], self.piece[s].numpy().copy())]
+        got = []
+        dsts = range(self.world) if self.result_ranks is None else self.result_ranks
+        for dst in dsts:
+            bufs = [self.torch.empty_like(self.piece[s]) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(self.piece[s], bufs, dst=dst, group=self.group)
+            if self.rank == dst:
+                got = [(k, bufs[r].numpy()) for r, k in enumerate(ks) if k < len(self.plan)]
+        return got
+
+    def last_tail(self, k, owner):
+        return np.stack(self.tail)          # every rank ran the whole chain on key frames that include slots 24..31: already here
+
+
 # ------------------------------------------------------------------ stitching
 def compute_scale_and_shift(prediction: np.ndarray, target: np.ndarray) -> Tuple[float, float]:
     """Closed-form least squares target ~ scale*prediction + shift over all pixels
@@ -178,10 +322,12 @@ def stitch_windows(window_depths: Sequence[np.ndarray], n_frames: int, metric: b
 
 
 # ------------------------------------------------------------------ host driver (CPU rehearsal of the multi-rank schedule)
-def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray], metric: bool = False, group=None) -> np.ndarray:
+def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray], metric: bool = False, group=None, exchange: str = "windows",
+                result_ranks=None):
     """infer_video_depth's schedule on the host: `window_fn(frames_u8[32,H0,W0,3]) -> float32 [32,H0,W0]` per window, the
     same `drive_windows` rounds / ring / gather order the device path uses (gloo on CPU tensors instead of RCCL), then the
-    numpy stitcher. Every rank returns the full sequence. Used by the CPU tests (world size 1, 2, 3)."""
+    numpy stitcher. Every rank returns the full sequence. Used by the CPU tests (world size 1, 2, 3).
+    exchange="keys": the key-frame schedule (drive_windows_keys); ranks outside result_ranks return None."""
     import torch
     import torch.distributed as dist
 
@@ -190,6 +336,17 @@ def run_windows(frames: np.ndarray, window_fn: Callable[[np.ndarray], np.ndarray
     plan = plan_windows(n)
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     rank = dist.get_rank(group) if world > 1 else 0
+    if exchange == "keys":
+        ops = HostKeyOps(frames, plan, window_fn, metric, world, rank, result_ranks, group)
+        out = np.zeros((n, H0, W0), dtype=np.float32) if (result_ranks is None or rank in result_ranks) else None
+        seen = np.zeros(n, dtype=np.int32)
+        for pos, cnt, piece in drive_windows_keys(len(plan), world, rank, ops, result_ranks):
+            hi = min(pos + cnt, n)
+            if hi > pos:
+                out[pos:hi] = piece[:hi - pos]
+                seen[pos:hi] += 1
+        assert out is None or (seen == 1).all(), "every output frame exactly once"
+        return out
     send = [torch.zeros(INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)]
     recv = [torch.empty(world, INFER_LEN, H0, W0, dtype=torch.float32) for _ in range(2)] if world > 1 else None
 

@@ -49,6 +49,11 @@ class VideoDepthAnything:
         # (each process returns the full sequence); e.g. (0,) lets the other ranks skip the stitch and its device-to-host
         # copies - they return (None, target_fps).
         self.result_ranks = None
+        # What the ranks exchange per round: "windows" = whole windows all-gathered, every result rank stitches the video
+        # (north_star's form); "keys" = 11 key frames per window all-gathered, the scale/shift chain on every rank, each rank
+        # finalises its own windows and only final frames travel to the result ranks (scheduler.drive_windows_keys).
+        # Both give bit-identical videos.
+        self.exchange = "windows"
 
     # ---- nn.Module-like surface used by the callers -------------------------------------------
     def load_state_dict(self, state_dict, strict=True):
@@ -189,9 +194,10 @@ class VideoDepthAnything:
                 lanes[s].wait_event(freed[s])
             used[s] = True
 
-        def window_depth(k, s):
+        def window_depth(k, s, keys=None):
             """Window k on lane s: gather (+ resize to the network size) + normalise (video_depth.py:197-201,
-            util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into send[s] [32,H0,W0]."""
+            util/transform.py:109-147), forward, resize to the source size (video_depth.py:207-208) into send[s] [32,H0,W0]
+            (keys: the window's KEY_SLOTS frames are copied there too - three contiguous runs)."""
             ensure(k)
             lane = lanes[s]
             lane.wait_stream(upload)
@@ -207,6 +213,10 @@ class VideoDepthAnything:
                     ops.gather_resize_normalize_u8(video, idx, xin[s], INFER_LEN, H0, W0, H, W)
                 depth = eng.forward(xin[s], fp32=fp32, slot=s)                   # [1,32,H,W] fp32
                 ops.bilinear_plane(depth.view(INFER_LEN, H, W), send[s], INFER_LEN, H, W, H0, W0)
+                if keys is not None:
+                    keys[0:2].copy_(send[s][0:2])
+                    keys[2].copy_(send[s][12])
+                    keys[3:].copy_(send[s][INFER_LEN - 8:])
                 computed[s].record(lane)
             pos = mine.index(k)
             ensure(mine[pos + 1] if pos + 1 < len(mine) else None)              # overlaps this window's compute
@@ -232,6 +242,36 @@ class VideoDepthAnything:
 
         def release(s):
             freed[s].record(compute)
+
+        if self.exchange == "keys":
+            from .scheduler import KEY_SLOTS, drive_windows_keys
+            from .stitch import DeviceKeyOps, collect_pieces
+            assert tuple(KEY_SLOTS) == (0, 1, 12) + tuple(range(INFER_LEN - 8, INFER_LEN))
+
+            def gather_keys(s, out, inp):
+                acquire(s)
+                with torch.cuda.stream(lanes[s]):
+                    if world > 1:
+                        h = _all_gather(out, inp)
+                        if h is not None:
+                            h.wait()
+                    else:
+                        out[0].copy_(inp)
+                    computed[s].record(lanes[s])
+                return None
+
+            kops = DeviceKeyOps(send, H0, W0, dev, self.METRIC, world, rank, len(plan), self.result_ranks, window_depth, ready, release,
+                                gather_keys, acquire)
+            pieces = drive_windows_keys(len(plan), world, rank, kops, self.result_ranks)
+            if self.result_ranks is not None and rank not in self.result_ranks:
+                for _ in pieces:
+                    pass
+                torch.cuda.synchronize(dev)
+                return None, target_fps
+            depths = collect_pieces(pieces, n, H0, W0, dev, on_copied=kops.copied)
+            for lane in lanes:
+                compute.wait_stream(lane)
+            return depths, target_fps
 
         # One process per GPU: rank r computes windows r, r + world, ... with no data-path collective; after each round the
         # finished windows are all-gathered (asynchronously, under the next round's compute) and handed to the stitcher in window
