@@ -185,7 +185,7 @@ int vda_attention_f32(const float* qkv, float* out, int B, int N, int heads, vda
  * kernel (V^T fragments via ds_read_b64_tr_b16, scalar softmax math); 2 = packed fp32 softmax math; 0 = scalar LDS
  * reads of V (cross-check); 3 = row sums through the matrix pipe; 4 / 5 = running max through the matrix pipe (without / with 3);
  * 7 = software-pipelined form (next tile's score MFMAs inside the softmax; three waves per SIMD);
- * 10 + k = timing ablations (WRONG results: no exp / max / row sums / PV MFMAs / 1 of 4 QK k-steps), tools/attn_one.py. */
+ * 11 = 10 with LDS counters in place of the per-tile workgroup barrier (A/B); 20 + k = timing ablations (WRONG results: no exp / max / row sums / PV MFMAs / 1 of 4 QK k-steps), tools/attn_one.py. */
 int vda_attention_set_variant(int v);
 
 /* Temporal attention across T frames per pixel (motion_module.py:232-295,

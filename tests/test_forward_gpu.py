@@ -29,8 +29,10 @@ TOL32 = 1e-3
 TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.nonsquare.depth": 1.4e-3, "vits.518.depth_sub": 3.0e-3,
          "vits.518.row_sums": 2.5e-3, "video.relative": 3.6e-3, "video.metric": 4.3e-3, "vitl.2x518": 2.4e-3, "vits.4x518": 7e-4,
          "vitl.t32": 1.3e-3, "vitl.metric_video": 9e-4, "resize_video": 4.4e-3, "tiny_cls.depth": 3.7e-3,
-         # round 3: the BENCHMARKED workloads at their own size (first measured at the commit that added them, bound = 2x)
-         "vits.32x518": 1.0e-3, "vitl.32x518": 2.4e-3,
+         # round 3: the BENCHMARKED workloads at their own size: measured 9.2e-4 (ViT-S) / 2.0e-3 (ViT-L), bound = 2x. The reference's
+         # OWN autocast-fp16 path (the oracle's torch ops on the GPU under torch.autocast, VDA_TEST_YARDSTICK=1) is 1.86e-3 / 4.5e-3
+         # from the fp32 reference on the same clips: both bounds stay below it
+         "vits.32x518": 1.8e-3, "vitl.32x518": 4.0e-3,
          # ... and the outlier-activation state dicts (tests/_outliers.py): see test_outlier_activations
          # (2x the larger of the two LayerNorm forms, measured: channels 4.0e-3 / 5.1e-3, offset 2.6e-3 / 3.2e-3, both 3.3e-3 / 4.1e-3 for
          # fold / standalone; the reference's OWN autocast-fp16 path on the same streams: 9.8e-3, 4.3e-2, 8.0e-3)

@@ -492,7 +492,7 @@ def attn_ref(qkv, B, N, H):
     return (a @ v).transpose(1, 2).reshape(B, N, H * 64)
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 2, 3, 0, 4, 5, 7, 8, 9, 10])
+@pytest.mark.parametrize("variant", [-1, 1, 2, 3, 0, 4, 5, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("B,N,H", [(2, 13, 2), (1, 64, 1), (2, 200, 3), (1, 1370, 2)])
 def test_attention(ops, B, N, H, variant):
     from video_depth_anything_amd._lib import lib
@@ -525,7 +525,7 @@ def test_attention_benchmark_grid(ops, H):
         close(o[b_, :, h_ * 64:(h_ + 1) * 64], a, rtol=3e-3, atol=3e-3, what=f"attention frame {b_} head {h_}")
 
 
-@pytest.mark.parametrize("variant", [-1, 1, 8, 9, 10])
+@pytest.mark.parametrize("variant", [-1, 1, 8, 9, 10, 11])
 def test_attention_spiked_scores(ops, variant):
     """Online-softmax rescale path: keys that dominate late in the sequence (guide rule 26), by a lot (far past the lazy
     threshold of the default kernel: 2^6), by a little (inside it: the reference point stays, p grows up to 64) and in

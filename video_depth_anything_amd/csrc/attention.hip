@@ -662,9 +662,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 //     A wave whose sums say otherwise (spiked scores; always the first tile, whose reference point is 0) takes the slow path:
 //     the scores are formed again from the K tile still in LDS, their maximum moves the reference point exactly as in
 //     attn_cm_kernel, and the tile's p is recomputed. Decided per lane pair (one query): neighbours never change a row's result.
+//
+// FLAGS (variant 11, A/B): the per-tile workgroup barrier replaced by two pairs of LDS counters. A wave counts itself in on
+// full[b] when its own pieces of the tile in buffer b have landed and on empty[b] when it has finished reading that buffer; it
+// waits on full[b] before reading and on empty[b ^ 1] before re-staging. The four waves of a workgroup sit on four different
+// SIMDs, each shared with three other workgroups' waves, so they drift apart: with s_barrier every tile ends at the slowest wave
+// (PMC: 29 % of wave-cycles parked), with counters a wave may run up to a tile ahead of the slowest.
+template <bool FLAGS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) attn_cs_kernel(const h16* __restrict__ qkv, h16* __restrict__ out, int N, int H,
                                                                                             int nqb, int total_blocks) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + (FLAGS ? 16 : 0)];
+    volatile VDA_LDS_AS int* const flags = (volatile VDA_LDS_AS int*)(smem + 2 * STAGE_BYTES);      // full[0], full[1], empty[0], empty[1]
+    if constexpr (FLAGS) {
+        if (threadIdx.x < 4) flags[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    auto count_in = [&](int idx) {                  // one lane per wave: this wave is through
+        if constexpr (FLAGS) {
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add((VDA_LDS_AS int*)(flags + idx), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    auto wait_for = [&](int idx, int target) {      // all four waves are through (counters only grow)
+        if constexpr (FLAGS) {
+            while (__builtin_amdgcn_readfirstlane(flags[idx]) < target) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
+    };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -729,12 +752,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     int cur = 0;
     for (int kt = 0; kt < nt; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        if constexpr (FLAGS) {
+            const int use = (kt >> 1) + 1;                               // how many tiles buffer `cur` has held, this one included
+            count_in(cur);                                               // my pieces of tile kt are in buffer cur
+            if (kt + 1 < nt) {
+                if (kt >= 1) wait_for(2 + (cur ^ 1), 4 * ((kt - 1) / 2 + 1));    // everyone has finished reading tile kt - 1
+                stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+            }
+            wait_for(cur, 4 * use);                                      // everyone's pieces of tile kt have landed
+        } else {
+            __syncthreads();
+            if (kt + 1 < nt) stage(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        }
         const char* Kt = smem + cur * STAGE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
+        const int done_idx = 2 + cur;
         cur ^= 1;
-        if (!wave_active) continue;
+        if (!wave_active) {
+            count_in(done_idx);                                          // (reads nothing)
+            continue;
+        }
 
         const bool last_partial = __builtin_amdgcn_readfirstlane((int)(kt == nt - 1 && (N % BKV) != 0)) != 0;
         // scores relative to the reference point: S^T - m = K . Q^T + (-m); keys past N masked
@@ -828,6 +865,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kstep], acc_o[c], 0, 0, 0);
             }
         }
+        if constexpr (FLAGS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my reads of the buffer are done (LDS returns in order)
+            count_in(done_idx);
+        }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -871,13 +912,15 @@ extern "C" int vda_attention_f16(const void* qkv, void* out, int B, int N, int h
     hipStream_t s = (hipStream_t)stream;
     const int g_attn_variant = ::g_attn_variant < 0 ? VDA_ATTN_DEFAULT : ::g_attn_variant;      // (shadows the global inside this call)
 #define VDA_ATTN_ABL(K)                                                                                                                        \
-    if (g_attn_variant == 10 + K)                                                                                                              \
+    if (g_attn_variant == 20 + K)                                                                                                              \
         hipLaunchKernelGGL((attn_kernel<true, false, false, false, K>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total); \
     else
     VDA_ATTN_ABL(1) VDA_ATTN_ABL(2) VDA_ATTN_ABL(3) VDA_ATTN_ABL(4) VDA_ATTN_ABL(5)
 #undef VDA_ATTN_ABL
-    if (g_attn_variant == 10)
-        hipLaunchKernelGGL(attn_cs_kernel, dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    if (g_attn_variant == 11)
+        hipLaunchKernelGGL((attn_cs_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
+    else if (g_attn_variant == 10)
+        hipLaunchKernelGGL((attn_cs_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 8)
         hipLaunchKernelGGL((attn_cm_kernel<0>), dim3((unsigned)total), dim3(256), 0, s, (const h16*)qkv, (h16*)out, N, heads, nqb, (int)total);
     else if (g_attn_variant == 9)
