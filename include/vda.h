@@ -108,7 +108,8 @@ int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
  * 32x32x16 MFMA; 3 / 4 = the same tiles on 16x16x32 MFMA, one barrier per K tile; 5 = 256x256 8-phase two-group schedule (what -1
  * uses for wide N), 5 + 16*flags = the same with debug switches (gemm8p_kernel.h: 1 early next-tile prefetch, 2 clock stamps,
  * 4 / 8 prefetch placement, 16 no start stagger), 5 + 32*s = K-loop schedule s; 7 = patch-in-LDS direct 3x3 conv where it
- * applies; 8 = 192x128 tiles on six waves; 9 = 256x128 8-phase. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
+ * applies; 8 = 192x128 tiles on six waves; 9 = 256x128 8-phase; 10 = 192x384 tiles on twelve waves where N is a multiple of 384
+ * (an A/B form: not what -1 picks, see gemm.hip); 5 + 16*64 = 8-phase on 192x256 tiles where built. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
  * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 0, 1). */
 int vda_gemm_set_variant(int v);
 /* Row split of a large dense GEMM on the current device: returns M1 <= M. Rows [0, M1) fill whole rounds of 256 x 256 tiles on the

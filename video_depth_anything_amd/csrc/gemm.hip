@@ -217,6 +217,7 @@ int vda_gemm256s_dense_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_dense_bn128_bm192(const vda_gemm_args& a, hipStream_t s);      // 192 x 128 tiles, six waves; -1 = epilogue not built
+int vda_gemm256s_dense_bn384_bm192(const vda_gemm_args& a, hipStream_t s);      // 192 x 384 tiles, twelve waves; -1 = epilogue not built
 
 // gemm8p_*.hip: 256 x 256 tile, 8-phase two-group schedule
 int vda_gemm8p_dense_bn256(const vda_gemm_args& a, hipStream_t s);
@@ -433,7 +434,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
     bool eight = g_gemm_variant >= 5 && (g_gemm_variant & 15) == 5;      // upper bits: A/B switches of the 8-phase kernel
     if (eight) big = 256;
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
-    if (g_gemm_variant == 2 || g_gemm_variant == 4 || g_gemm_variant == 8) big = 128;
+    if (g_gemm_variant == 2 || g_gemm_variant == 4 || g_gemm_variant == 8 || g_gemm_variant == 10) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
     if (g_gemm_variant == 9) {               // 9 = 256x128 8-phase two-group schedule
         eight = true;
@@ -502,6 +503,23 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
                 snprintf(name192, sizeof(name192), "gemm8p_kernel<256, %d, %d, 1, 192>", a.a_mode, a.epilogue);
                 g_last_kernel = name192;
                 return rc192;
+            }
+        }
+        // N a multiple of 384 (ViT-S's embedding width: proj / fc2 N = 384, qkv N = 1152): 192 x 384 tiles on twelve waves, one tile
+        // per row panel and column third - A and the residual rows are read once, 229 row panels are one round of the chip.
+        // Built, tested (variant 10) and NOT the default (VDA_GEMM_BN384=1 enables it): in-process A/B (tools/gemm_ab.py
+        // AB_SHAPES=vits -1,3,8,10, round 3) it wins with a plain epilogue (fc2's shape 70.7 -> 52.4 us) and not with the ones the
+        // model uses - split residual: fc2 80.0 -> 79.6, proj 38.2 -> 43.2 us; qkv + LayerNorm 61.5 -> 64.1 - and the ViT-S forward is
+        // 8.86 -> 9.15 ms with it: a single round puts every CU's residual epilogue (270 MB for fc2) on HBM at the same moment with no
+        // K loop anywhere to hide behind.
+        static const int wide384 = getenv("VDA_GEMM_BN384") ? atoi(getenv("VDA_GEMM_BN384")) : 0;
+        if (a.a_mode == VDA_A_DENSE && a.N % 384 == 0 && ((g_gemm_variant < 0 && wide384 && !eight && a.N <= 1152) || g_gemm_variant == 10)) {
+            const int rc384 = vda_gemm256s_dense_bn384_bm192(a8, s);
+            if (rc384 >= 0) {
+                static thread_local char name384[64];
+                snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192>", a.a_mode, a.epilogue);
+                g_last_kernel = name384;
+                return rc384;
             }
         }
         if (tall192) {

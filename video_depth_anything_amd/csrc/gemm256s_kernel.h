@@ -28,11 +28,16 @@ constexpr int ROW_BYTES = BK * 2;
 // BM = 256 on 8 waves, or (BN = 128 only) BM = 192 on 6 waves (3 x 2, the same 64 x 64 wave tile): the tile for problems whose
 // 256-row tile count sits just above a multiple of the CU count - ViT-S's proj / fc2: 172 x 3 = 516 tiles = 2.016 rounds run as
 // 3; 229 x 3 = 687 tiles of 3/4 the size = 2.68 rounds run as 3 x 0.75 = 2.25.
+// [r3] BN = 384 (BM = 192, twelve waves as 2 x 6, the same 96 x 64 wave tile as the 192 x 256 8-phase kernel): ONE tile spans
+// ViT-S's whole embedding width, so proj / fc2 read their A panel and their residual rows once, and 43 840 rows are 229 tiles = one
+// round of the chip (687 tiles of 192 x 128 ran as 3). qkv (N = 1152) is three such column tiles. 144 KiB of pipeline buffers:
+// the epilogue stages through BOTH of them (12 x 8 KiB), so this variant issues the next tile's first K tile after its epilogue.
 template <int BN, int AMODE, int EPI, int BM = 256>
-__global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_args p) {
-    static_assert(BM == 256 || (BM == 192 && BN == 128), "tile heights: 256, or 192 with BN = 128");
-    constexpr int NW = BM / 32;                    // waves: 8, or 6
-    constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
+__global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kernel(const vda_gemm_args p) {
+    static_assert(BM == 256 || (BM == 192 && (BN == 128 || BN == 384)), "tile heights: 256, or 192 with BN = 128 / 384");
+    static_assert(BN != 384 || (BM == 192 && AMODE == VDA_A_DENSE), "384 columns: 192 rows, dense A");
+    constexpr int NW = BN == 384 ? 12 : BM / 32;   // waves: 8, or 6, or 12
+    constexpr int WN = BN == 384 ? 6 : BN == 256 ? 4 : 2;          // waves along N
     constexpr int WM = NW / WN;                    // waves along M
     constexpr int WTM = BM / WM, WTN = BN / WN;    // wave tile: 128x64 (BN=256) or 64x64 (BN=128)
     constexpr int MI = WTM / 16, NJ = WTN / 16;    // 16x16 subtiles per wave
@@ -171,7 +176,8 @@ __global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_a
     const int nt = p.K / BK;
     static_assert(WTN == 64, "epilogue staging assumes a 64-column wave tile");
     // epilogue staging (NW waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
-    constexpr int STG_OFF = (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
+    constexpr bool LATE_NEXT = NW * 8192 > STAGE && 2 * STAGE + NW * 8192 > 160 * 1024;   // staging needs both buffers (BN = 384)
+    constexpr int STG_OFF = LATE_NEXT ? 0 : (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
     char* stg = smem + STG_OFF + wave * 8192;
 
     int tile = tile_of(0);
@@ -252,7 +258,7 @@ __global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_a
         // After the loop's last barrier nobody reads the pipeline buffers any more: start the NEXT tile's first
         // K tile now, so its HBM/L2 latency is covered by this tile's epilogue.
         const int next = tile_of(round + 1);
-        if (next < ntiles) {
+        if (!LATE_NEXT && next < ntiles) {
             set_sources(next);
             tap_of(0);
             stage(0, smem);
@@ -351,6 +357,11 @@ __global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_a
         }
         // Every wave is done with its staging slice before the next tile's stage(1) overwrites buffer 1.
         __syncthreads();
+        if (LATE_NEXT && next < ntiles) {       // (staging used both buffers: the next tile's first K tile starts here)
+            set_sources(next);
+            tap_of(0);
+            stage(0, smem);
+        }
         tile = next;
     }
 }
@@ -358,7 +369,8 @@ __global__ void __launch_bounds__(BM / 32 * 64) gemm256s_kernel(const vda_gemm_a
 template <int BN, int AMODE, int EPI, int BM = 256>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
-    constexpr int smem = stage_bytes >= 8 * 8192 ? 2 * stage_bytes : 2 * stage_bytes + BM / 32 * 8192;
+    constexpr int nthreads = BN == 384 ? 768 : BM / 32 * 64;
+    constexpr int smem = (BN == 384 || stage_bytes >= 8 * 8192) ? 2 * stage_bytes : 2 * stage_bytes + BM / 32 * 8192;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static VdaKernelDeviceState dev_state;
     const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI, BM>), smem, dev_state);
@@ -366,7 +378,7 @@ int launch256(const vda_gemm_args& a, hipStream_t s) {
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI, BM>), dim3(grid), dim3(BM / 32 * 64), smem, s, a);
+    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI, BM>), dim3(grid), dim3(nthreads), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
@@ -394,14 +406,29 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
 }
 
 // 192-row tiles (BN = 128, dense A): the epilogues the encoder uses
-inline int launch_dense_bm192(const vda_gemm_args& a, hipStream_t s) {
+template <int BN>        // (a template only so that the kernels are instantiated in the one translation unit that calls it)
+int launch_dense_bm192(const vda_gemm_args& a, hipStream_t s) {
     switch (a.epilogue) {
-        case VDA_EPI_BIAS_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_BIAS_F16, 192>(a, s);
-        case VDA_EPI_BIAS_GELU_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_BIAS_GELU_F16, 192>(a, s);
-        case VDA_EPI_SCALE_RES_F32: return launch256<128, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32, 192>(a, s);
-        case VDA_EPI_SCALE_RES_SPLIT: return launch256<128, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT, 192>(a, s);
-        case VDA_EPI_LN_BIAS_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 192>(a, s);
-        case VDA_EPI_LN_GELU_F16: return launch256<128, VDA_A_DENSE, VDA_EPI_LN_GELU_F16, 192>(a, s);
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F16, 192>(a, s);
+        case VDA_EPI_BIAS_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_GELU_F16, 192>(a, s);
+        case VDA_EPI_SCALE_RES_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32, 192>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT, 192>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 192>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16, 192>(a, s);
+        default: break;
+    }
+    return -1;
+}
+
+// 192 x 384 tiles on twelve waves (dense A): ViT-S's embedding width in one tile
+template <int BN>
+int launch_dense_bn384(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F16, 192>(a, s);
+        case VDA_EPI_SCALE_RES_F32: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_F32, 192>(a, s);
+        case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT, 192>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 192>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16, 192>(a, s);
         default: break;
     }
     return -1;
