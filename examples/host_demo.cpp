@@ -5,7 +5,7 @@
 //
 //   host_demo <model.bin> <input.bin> <output.bin> <precision: 0 = fp16 operands, 1 = fp32 operands>
 //
-// model.bin : vda_config (14 x int32), int32 n, then n x { int32 name_len, name, int32 ndim, int64 dims[ndim], float data[] }
+// model.bin : vda_config (16 x int32), int32 n, then n x { int32 name_len, name, int32 ndim, int64 dims[ndim], float data[] }
 // input.bin : int32 B, T, H, W, then float x[B,T,3,H,W] (normalised frames)
 // output.bin: float depth[B,T,H,W]
 // tests/test_host_demo_gpu.py writes the inputs from Python, runs this program and requires its output to be bit-identical to

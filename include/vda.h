@@ -166,6 +166,12 @@ int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const flo
 int vda_fold_ln_weight(const float* W, const float* bias, const float* ln_w, const float* ln_b, void* Wf, float* c1, float* c2,
                        int N, int K, vda_stream_t stream);
 
+/* pe = 'rope' (motion_module.py:254-257, motion_module/attention.py:403-429): channel pairs (2i, 2i+1) of the q and k thirds of the
+ * fused projection qkv [T*hw, 3*C] (frame-major rows) rotated in place by  frame * 10000^(-2i/C)  (fp32 arithmetic, over the FULL
+ * width C, before the head split); v is untouched. */
+int vda_rope_qk_f16(void* qkv, int T, int hw, int C, vda_stream_t stream);
+int vda_rope_qk_f32(float* qkv, int T, int hw, int C, vda_stream_t stream);
+
 /* GroupNorm(32 groups) per frame on NHWC fp16 [frames, hw, C] -> fp16 [frames*hw, C]
  * (motion_module.py:84,110). `partial` is workspace of frames*chunks*groups*2 floats. */
 int vda_groupnorm_nhwc_f16(const void* in, void* out, const float* w, const float* b, float eps,
@@ -297,6 +303,10 @@ typedef struct vda_config {
     int32_t out_channels[4];  /* 48,96,192,384 / 256,512,1024,1024 */
     int32_t num_frames;       /* 32: temporal window (pos_encoder.pe rows) */
     int32_t use_clstoken;     /* 0 (every released config) / 1: head.readout_projects fold the cls token in, dpt.py:92-98 */
+    int32_t use_bn;           /* 0 (every released config) / 1: BatchNorm2d after each conv of the fusion blocks' ResidualConvUnits
+                                 (util/blocks.py:60-62,80-86; inference = an affine per channel, folded into the conv at pack time) */
+    int32_t pe_rope;          /* 0 = pe 'ape' (every released config): sinusoidal pos_encoder.pe added before q/k/v; 1 = pe 'rope':
+                                 no pe buffer in the checkpoint, q and k rotated per frame (motion_module.py:221-224,254-257) */
 } vda_config;
 
 enum vda_precision {

@@ -92,8 +92,8 @@ def build_reference(cfg, sd, ref_root):
             img_size=518, patch_size=14, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
             mlp_ratio=4, block_fn=partial(Block, attn_class=MemEffAttention), init_values=1.0, ffn_layer="mlp",
             block_chunks=0, num_register_tokens=0, interpolate_antialias=False, interpolate_offset=0.1)
-    m.head = DPTHeadTemporal(m.pretrained.embed_dim, cfg.features, False, out_channels=list(cfg.out_channels),
-                             use_clstoken=cfg.use_clstoken, num_frames=cfg.num_frames, pe="ape")
+    m.head = DPTHeadTemporal(m.pretrained.embed_dim, cfg.features, cfg.use_bn, out_channels=list(cfg.out_channels),
+                             use_clstoken=cfg.use_clstoken, num_frames=cfg.num_frames, pe=cfg.pe)
     m.load_state_dict(sd, strict=True)
     return m.eval()
 
@@ -239,6 +239,24 @@ def main():
     np.savez_compressed(os.path.join(OUT, "tiny_clstoken_forward.npz"), x=x.numpy(), depth=depth.numpy(), layer_1=store["layer_1"].numpy(),
                         layer_2=store["layer_2"].numpy(), sd_seed=4, sd_checksum=sd_checksum(sd))
     print("tiny_clstoken_forward", depth.shape, float(depth.mean()))
+
+    # ---- 4c / 4d. the two remaining constructor switches of video_depth.py:38-50 (no released configuration sets them): use_bn=True
+    # (BatchNorm2d after each conv of the fusion blocks' ResidualConvUnits, util/blocks.py:60-62,80-86; eval mode, random running
+    # statistics) and pe='rope' (rotary embedding of q and k in the temporal attention, motion_module.py:221-224,254-257)
+    for tag, kw, sd_seed, x_seed in (("tiny_bn_forward", dict(use_bn=True), 6, 105), ("tiny_rope_forward", dict(pe="rope"), 7, 106)):
+        cfg = get_config("tiny", **kw)
+        sd = synthetic_state_dict(cfg, seed=sd_seed)
+        model = build_reference(cfg, sd, "/root/reference")
+        x = torch.randn(1, 4, 3, 42, 56, generator=torch.Generator().manual_seed(x_seed))
+        store, hooks = capture_stages(model)
+        with torch.no_grad():
+            depth = model.forward(x)
+        for h in hooks:
+            h.remove()
+        np.savez_compressed(os.path.join(OUT, tag + ".npz"), x=x.numpy(), depth=depth.numpy(), path_2=store["path_2"].numpy(),
+                            path_1=store["path_1"].numpy(), layer_3=store["layer_3_bcthw"].permute(0, 2, 1, 3, 4).flatten(0, 1).numpy(), sd_seed=sd_seed,
+                            sd_checksum=sd_checksum(sd))
+        print(tag, depth.shape, float(depth.mean()))
 
     # ---- 5. stitcher maths directly (utils/util.py) -------------------------------
     from utils.util import compute_scale_and_shift, get_interpolate_frames

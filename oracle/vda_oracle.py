@@ -130,10 +130,24 @@ def temporal_attention(sd: SD, pre: str, h: Tensor, T: int, heads: int = 8) -> T
     BT, d, C = h.shape
     b = BT // T
     x = h.reshape(b, T, d, C).permute(0, 2, 1, 3).reshape(b * d, T, C)       # (b d) f c
-    x = x + sd[pre + "pos_encoder.pe"][:, :T]
+    rope = (pre + "pos_encoder.pe") not in sd                                 # pe='rope': no buffer in the checkpoint (motion_module.py:221-224)
+    if not rope:
+        x = x + sd[pre + "pos_encoder.pe"][:, :T]
     q = F.linear(x, sd[pre + "to_q.weight"])
     k = F.linear(x, sd[pre + "to_k.weight"])
     v = F.linear(x, sd[pre + "to_v.weight"])
+    if rope:
+        # motion_module.py:254-257 + motion_module/attention.py:403-429: channel pairs (2i, 2i+1) of q and k, over the FULL width C
+        # (before the head split), rotated by frame_index * 10000^(-2i/C)
+        freqs = 1.0 / (10000.0 ** (torch.arange(0, C, 2)[: C // 2].float() / C))
+        ang = torch.outer(torch.arange(T, dtype=torch.float32), freqs)        # [T, C/2]
+        cos, sin = torch.cos(ang), torch.sin(ang)
+
+        def rot(t):
+            a, bb = t.float().reshape(b * d, T, C // 2, 2).unbind(-1)
+            return torch.stack((a * cos - bb * sin, a * sin + bb * cos), dim=-1).flatten(2).to(t.dtype)
+
+        q, k = rot(q), rot(k)
     hd = C // heads
 
     def split(t):
@@ -175,8 +189,13 @@ def _conv(sd: SD, name: str, x: Tensor, stride=1, padding=1) -> Tensor:
 
 def residual_conv_unit(sd: SD, pre: str, x: Tensor) -> Tensor:
     """util/blocks.py:68-91; activation is nn.ReLU(False) so the skip keeps the raw x."""
-    y = _conv(sd, pre + "conv1", F.relu(x))
-    y = _conv(sd, pre + "conv2", F.relu(y))
+    def bn(y, n):                                                             # use_bn=True (util/blocks.py:80-81,85-86), eval mode
+        if pre + n + ".weight" not in sd:
+            return y
+        return F.batch_norm(y, sd[pre + n + ".running_mean"], sd[pre + n + ".running_var"], sd[pre + n + ".weight"], sd[pre + n + ".bias"], False, 0.0, 1e-5)
+
+    y = bn(_conv(sd, pre + "conv1", F.relu(x)), "bn1")
+    y = bn(_conv(sd, pre + "conv2", F.relu(y)), "bn2")
     return y + x
 
 

@@ -38,13 +38,14 @@ def test_library_exports_every_declared_symbol(libpath):
     lib = ctypes.CDLL(libpath)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libvda_hip.so lacks {missing}"
-    assert lib.vda_abi_version() == 6
+    assert lib.vda_abi_version() == 7
 
 
 def test_binding_table_matches_header(libpath):
     from video_depth_anything_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     assert ctypes.sizeof(_lib.GemmArgs) == 12 * 8 + 22 * 4
+    assert ctypes.sizeof(_lib.Config) == 16 * 4              # vda_config: what examples/host_demo.cpp reads from model.bin
 
 
 def test_refusal_needs_no_gpu(libpath):

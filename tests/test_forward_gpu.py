@@ -868,3 +868,39 @@ def test_bench_rccl_calls_at_world_size_one():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert d["config"]["backend"] == "nccl" and d["config"]["world"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
+
+
+@pytest.mark.parametrize("fp32", PRECISIONS)
+@pytest.mark.parametrize("name,kw", [("tiny_bn_forward.npz", {"use_bn": True}), ("tiny_rope_forward.npz", {"pe": "rope"})], ids=["use_bn", "rope"])
+def test_golden_tiny_with_bn_and_with_rope(golden_dir, name, kw, fp32):
+    """use_bn=True (util/blocks.py:60-62,80-86) and pe='rope' (motion_module.py:221-224,254-257): reference-generated goldens, both
+    precisions, through the class and vda_forward. BatchNorm is folded into the convs when the weights are packed; the rotation
+    is vda_rope_qk on the fused projection."""
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import VideoDepthAnything
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    z = np.load(os.path.join(golden_dir, name))
+    cfg = get_config("tiny", **kw)
+    m = VideoDepthAnything(encoder="tiny", features=cfg.features, out_channels=list(cfg.out_channels), **kw)
+    assert m.cfg == cfg
+    sd = synthetic_state_dict(cfg, seed=int(z["sd_seed"]))
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    x = torch.from_numpy(z["x"]).cuda()
+    d = m.forward(x, fp32=fp32)
+    BT = x.shape[0] * x.shape[1]
+    tag = ("tiny_bn." if cfg.use_bn else "tiny_rope.") + ("f32." if fp32 else "")
+    for k, C in (("layer_3", cfg.out_channels[2]), ("path_2", cfg.features), ("path_1", cfg.features)):
+        t, h, w, Cp = m.engine.stage(k)
+        check_map(tag + k, nhwc_to_nchw(t, BT, h, w, Cp, C), z[k], tol_of("tiny.stage", fp32), tail=False)
+    check_map(tag + "depth", d.cpu().numpy(), z["depth"], tol_of("tiny_cls.depth", fp32))
+    # packing twice (the other precision, then this one again) folds the same BatchNorm again: same bits
+    m.forward(x, fp32=not fp32)
+    assert torch.equal(m.forward(x, fp32=fp32), d)
+    with pytest.raises(NotImplementedError):
+        m.python_engine()
+    # the strict inventory follows the switch
+    with pytest.raises(RuntimeError, match="Missing key" if cfg.use_bn else "Unexpected key"):
+        m.load_state_dict(synthetic_state_dict(get_config("tiny"), seed=1), strict=True)
+    with pytest.raises(NotImplementedError):
+        VideoDepthAnything(encoder="tiny", pe="alibi")

@@ -16,7 +16,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def write_model(path, cfg, sd):
     with open(path, "wb") as f:
-        f.write(struct.pack("<14i", cfg.embed_dim, cfg.depth, cfg.num_heads, *cfg.taps, cfg.features, *cfg.out_channels, cfg.num_frames, int(cfg.use_clstoken)))
+        f.write(struct.pack("<16i", cfg.embed_dim, cfg.depth, cfg.num_heads, *cfg.taps, cfg.features, *cfg.out_channels, cfg.num_frames, int(cfg.use_clstoken),
+                            int(cfg.use_bn), int(cfg.pe == "rope")))
         f.write(struct.pack("<i", len(sd)))
         for name, t in sd.items():
             nb = name.encode()
@@ -60,7 +61,7 @@ def test_cpp_host_reports_state_dict_errors(tmp_path):
     sd = synthetic_state_dict(cfg, seed=3)
     write_model(tmp_path / "model.bin", cfg, sd)
     raw = bytearray(open(tmp_path / "model.bin", "rb").read())
-    raw[56:60] = struct.pack("<i", len(sd) - 1)          # claim one tensor fewer than the handle expects
+    raw[64:68] = struct.pack("<i", len(sd) - 1)          # claim one tensor fewer than the handle expects
     open(tmp_path / "model.bin", "wb").write(raw)
     open(tmp_path / "input.bin", "wb").write(struct.pack("<4i", 1, 1, 14, 14) + np.zeros(3 * 14 * 14, np.float32).tobytes())
     r = subprocess.run([exe, str(tmp_path / "model.bin"), str(tmp_path / "input.bin"), str(tmp_path / "out.bin"), "0"],

@@ -761,3 +761,27 @@ def test_gemm_rows_are_position_independent(ops, gemm_variant, epi_name):
     ops.gemm(A, W, out, epi, **kw)
     torch.cuda.synchronize()
     assert torch.equal(out[:M1], out[M1:]), f"{int((out[:M1] != out[M1:]).sum())} elements depend on the row's position"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32], ids=["f16", "f32"])
+@pytest.mark.parametrize("T,hw,C", [(32, 37 * 37, 1024), (32, 19 * 19, 1024), (5, 3 * 4, 64), (32, 37 * 37, 192)])
+def test_rope_rotation_of_q_and_k(ops, T, hw, C, dtype):
+    """pe='rope' (motion_module/attention.py:403-429): q, k thirds of qkv rotated pairwise by frame * 10000^(-2i/C); v untouched.
+    Reference: the complex product in fp64, as precompute_freqs_cis / apply_rotary_emb state it."""
+    g = torch.Generator().manual_seed(T * 1000 + C)
+    qkv = torch.randn(T * hw, 3 * C, generator=g).to(dtype)
+    ref = qkv.double().clone()
+    freqs = 1.0 / (10000.0 ** (torch.arange(0, C, 2, dtype=torch.float64)[: C // 2] / C))
+    ang = torch.outer(torch.arange(T, dtype=torch.float64), freqs)              # [T, C/2]
+    cis = torch.polar(torch.ones_like(ang), ang).repeat_interleave(hw, 0)       # [T*hw, C/2], frame-major rows
+    for part in range(2):
+        blk = ref[:, part * C:(part + 1) * C].reshape(T * hw, C // 2, 2)
+        rot = torch.view_as_real(torch.view_as_complex(blk.contiguous()) * cis).reshape(T * hw, C)
+        ref[:, part * C:(part + 1) * C] = rot
+    d = qkv.cuda()
+    ops.rope_qk(d, T, hw, C)
+    out = d.cpu()
+    assert torch.equal(out[:, 2 * C:], qkv[:, 2 * C:])
+    err = (out.double() - ref).abs().max().item()
+    # fp32: sincosf / expf of an angle up to 31 rad; fp16: one rounding of the result (|x| < ~5 -> ulp 4e-3)
+    assert err < (3e-5 if dtype == torch.float32 else 2.5e-3), err

@@ -117,3 +117,33 @@ def test_tiny_forward_with_clstoken_readout(golden_dir):
         d = O.forward(sd, cfg, torch.from_numpy(z["x"]), stages)
     assert rel_err(stages["layer_1"].numpy(), z["layer_1"]) < RTOL and rel_err(stages["layer_2"].numpy(), z["layer_2"]) < RTOL
     assert rel_err(d.numpy(), z["depth"]) < RTOL
+
+
+@pytest.mark.parametrize("name,kw", [("tiny_bn_forward.npz", {"use_bn": True}), ("tiny_rope_forward.npz", {"pe": "rope"})], ids=["use_bn", "rope"])
+def test_tiny_forward_with_bn_and_with_rope(golden_dir, name, kw):
+    """The two constructor switches no released config sets: use_bn=True (util/blocks.py:60-62,80-86; BatchNorm2d in eval mode
+    behind each conv of the ResidualConvUnits) and pe='rope' (motion_module.py:221-224,254-257; q and k rotated per frame).
+    Fixtures generated from the reference's modules (oracle/gen_golden.py sections 4c / 4d)."""
+    z = load(golden_dir, name)
+    cfg = get_config("tiny", **kw)
+    sd = seeded_sd(cfg, z)
+    if cfg.use_bn:
+        k = "head.scratch.refinenet3.resConfUnit2.bn1.running_var"
+        assert k in sd and sd[k].min() > 0 and sd[k.replace("running_var", "num_batches_tracked")].dtype == torch.int64
+    else:
+        assert not any(k.endswith("pos_encoder.pe") for k in sd)
+    stages = {}
+    with torch.no_grad():
+        d = O.forward(sd, cfg, torch.from_numpy(z["x"]), stages)
+    for k in ("layer_3", "path_2", "path_1"):
+        assert rel_err(stages[k].numpy(), z[k]) < RTOL, k
+    assert rel_err(d.numpy(), z["depth"]) < RTOL
+    # the switch matters: the default model on the same weights (minus the extra keys) gives another answer
+    base = get_config("tiny")
+    from video_depth_anything_amd.weights import state_dict_spec, synthetic_state_dict
+    plain = {k: v for k, v in sd.items() if k in state_dict_spec(base)}
+    for k, v in synthetic_state_dict(base, seed=int(z["sd_seed"])).items():
+        plain.setdefault(k, v)                         # rope: the 'ape' model needs a pe buffer
+    with torch.no_grad():
+        d0 = O.forward(plain, base, torch.from_numpy(z["x"]))
+    assert rel_err(d0.numpy(), z["depth"]) > 1e-3

@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
 class Config(C.Structure):
     """vda_config (include/vda.h)."""
     _fields_ = [("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32), ("taps", C.c_int32 * 4),
-                ("features", C.c_int32), ("out_channels", C.c_int32 * 4), ("num_frames", C.c_int32), ("use_clstoken", C.c_int32)]
+                ("features", C.c_int32), ("out_channels", C.c_int32 * 4), ("num_frames", C.c_int32), ("use_clstoken", C.c_int32),
+                ("use_bn", C.c_int32), ("pe_rope", C.c_int32)]
 
 
 PREC_F16, PREC_F32 = 0, 1
@@ -62,6 +63,8 @@ SIGNATURES = {
     "vda_temporal_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_temporal_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_temporal_attention_set_variant": (_i, [_i]),
+    "vda_rope_qk_f16": (_i, [_vp, _i, _i, _i, _vp]),
+    "vda_rope_qk_f32": (_i, [_vp, _i, _i, _i, _vp]),
     "vda_bilinear_nhwc_f16": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_bilinear_nhwc_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_bilinear_plane_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

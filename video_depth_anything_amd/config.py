@@ -41,6 +41,8 @@ class ModelConfig:
     num_frames: int = 32
     mlp_ratio: int = 4
     use_clstoken: bool = False        # dpt.py:92-98,129-132: readout_projects (Linear 2D -> D + GELU over [patch, cls])
+    use_bn: bool = False              # util/blocks.py:60-62,80-86: BatchNorm2d after each conv of the fusion blocks' ResidualConvUnits
+    pe: str = "ape"                   # motion_module.py:214-224: 'ape' (sinusoidal buffer added before q/k/v) or 'rope' (rotary on q, k)
 
     @property
     def head_dim(self) -> int:
@@ -57,7 +59,10 @@ _CONFIGS = {
 }
 
 
-def get_config(encoder: str, features: int = None, out_channels=None, num_frames: int = 32, use_clstoken: bool = False) -> ModelConfig:
+def get_config(encoder: str, features: int = None, out_channels=None, num_frames: int = 32, use_clstoken: bool = False,
+               use_bn: bool = False, pe: str = "ape") -> ModelConfig:
+    if pe not in ("ape", "rope"):
+        raise NotImplementedError(pe)              # motion_module.py:226-227
     if encoder not in _CONFIGS:
         raise KeyError(encoder)
     base = _CONFIGS[encoder]
@@ -65,5 +70,5 @@ def get_config(encoder: str, features: int = None, out_channels=None, num_frames
         base.name, base.embed_dim, base.depth, base.num_heads, base.taps,
         base.features if features is None else int(features),
         base.out_channels if out_channels is None else tuple(int(c) for c in out_channels),
-        num_frames, base.mlp_ratio, bool(use_clstoken),
+        num_frames, base.mlp_ratio, bool(use_clstoken), bool(use_bn), pe,
     )

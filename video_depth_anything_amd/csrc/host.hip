@@ -219,6 +219,16 @@ void build_spec(const vda_config& c, Spec& s) {
                 put(k + ".weight", {F, F, 3, 3});
                 put(k + ".bias", {F});
             }
+        if (c.use_bn)                                                // util/blocks.py:60-62 (state_dict keys of nn.BatchNorm2d)
+            for (int u = 1; u <= 2; ++u)
+                for (int cc = 1; cc <= 2; ++cc) {
+                    const std::string k = r + "resConfUnit" + std::to_string(u) + ".bn" + std::to_string(cc) + ".";
+                    put(k + "weight", {F});
+                    put(k + "bias", {F});
+                    put(k + "running_mean", {F});
+                    put(k + "running_var", {F});
+                    put(k + "num_batches_tracked", {});
+                }
     }
     put(sc + "output_conv1.weight", {F / 2, F, 3, 3});
     put(sc + "output_conv1.bias", {F / 2});
@@ -242,7 +252,7 @@ void build_spec(const vda_config& c, Spec& s) {
             put(ab + "to_v.weight", {C, C});
             put(ab + "to_out.0.weight", {C, C});
             put(ab + "to_out.0.bias", {C});
-            put(ab + "pos_encoder.pe", {1, c.num_frames, C});
+            if (!c.pe_rope) put(ab + "pos_encoder.pe", {1, c.num_frames, C});     // (rope: freqs_cis is not a buffer, motion_module.py:221-224)
             put(tb + "norms." + std::to_string(a) + ".weight", {C});
             put(tb + "norms." + std::to_string(a) + ".bias", {C});
         }
@@ -273,6 +283,20 @@ int require_device(const vda_model* h, const char* what) {
         return 1;
     }
     return 0;
+}
+
+// use_bn: BatchNorm2d in inference is y = (x - running_mean) / sqrt(running_var + 1e-5) * weight + bias per channel, directly behind a
+// conv (util/blocks.py:80-81,85-86): folded into it, W'[co] = W[co] * s, b' = (b - running_mean) * s + bias, s = weight / sqrt(var + eps)
+__global__ void __launch_bounds__(256) fold_bn_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ g,
+                                                      const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv,
+                                                      float* __restrict__ Wo, float* __restrict__ bo, int Co, int per_co) {
+    const long long n = (long long)Co * per_co;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const int co = (int)(i / per_co);
+        const float sc = g[co] / sqrtf(rv[co] + 1e-5f);
+        Wo[i] = W[i] * sc;
+        if (i - (long long)co * per_co == 0) bo[co] = (b[co] - rm[co]) * sc + beta[co];
+    }
 }
 
 // ---- packing of one precision (T = h16 / float); vectors are packed once with the first precision
@@ -391,6 +415,25 @@ int pack_all(vda_model* h, int prec) {
             for (int cc = 1; cc <= 2; ++cc) {
                 const std::string rn = r + "resConfUnit" + std::to_string(u) + ".conv" + std::to_string(cc);
                 const std::string kn = k + "rcu" + std::to_string(u) + ".c" + std::to_string(cc);
+                if (c.use_bn) {
+                    // the folded fp32 conv replaces the raw one for packing (kept under its own key: a re-pack in the other
+                    // precision finds it again; a re-load of the state dict overwrites it)
+                    const std::string bn = r + "resConfUnit" + std::to_string(u) + ".bn" + std::to_string(cc) + ".";
+                    Raw& fw = h->raw[rn + ".weight.bn"];
+                    Raw& fb = h->raw[rn + ".bias.bn"];
+                    if (fw.d == nullptr) {
+                        void *pw = nullptr, *pb = nullptr;
+                        VDA_TRY(dev_alloc(h, (size_t)Fe * Fe * 9 * sizeof(float), &pw));
+                        VDA_TRY(dev_alloc(h, (size_t)Fe * sizeof(float), &pb));
+                        fw.d = (float*)pw, fw.n = (size_t)Fe * Fe * 9;
+                        fb.d = (float*)pb, fb.n = Fe;
+                    }
+                    hipLaunchKernelGGL(fold_bn_kernel, dim3(grid_for((size_t)Fe * Fe * 9)), dim3(256), 0, s, raw(rn + ".weight"), raw(rn + ".bias"), raw(bn + "weight"),
+                                       raw(bn + "bias"), raw(bn + "running_mean"), raw(bn + "running_var"), fw.d, fb.d, Fe, Fe * 9);
+                    VDA_TRY(conv(kn + ".w", rn + ".weight.bn", Fe, Fe, Fe, Fe));
+                    VDA_TRY(vecp(kn + ".b", rn + ".bias.bn", Fe, Fe));
+                    continue;
+                }
                 VDA_TRY(conv(kn + ".w", rn + ".weight", Fe, Fe, Fe, Fe));
                 VDA_TRY(vecp(kn + ".b", rn + ".bias", Fe, Fe));
             }
@@ -421,7 +464,7 @@ int pack_all(vda_model* h, int prec) {
                                    d + (size_t)j * Cc * Cc, Cc, Cc, Cc, Cc);
             VDA_TRY(lin(ka + "out.w", ab + "to_out.0.weight", Cc, Cc, Cc, Cc));
             VDA_TRY(vecp(ka + "out.b", ab + "to_out.0.bias", Cc, Cc));
-            VDA_TRY(vecp(ka + "pe", ab + "pos_encoder.pe", c.num_frames * Cc, c.num_frames * Cc));
+            if (!c.pe_rope) VDA_TRY(vecp(ka + "pe", ab + "pos_encoder.pe", c.num_frames * Cc, c.num_frames * Cc));
             VDA_TRY(vecp(ka + "ln.w", tb + "norms." + std::to_string(a) + ".weight", Cc, Cc));
             VDA_TRY(vecp(ka + "ln.b", tb + "norms." + std::to_string(a) + ".bias", Cc, Cc));
         }
@@ -581,10 +624,13 @@ struct Run {
         void* ao = act("tm_ao", (size_t)rows * Cc);
         for (int a = 0; a < 2; ++a) {
             const std::string ka = k + "a" + std::to_string(a) + ".";
-            VDA_TRY(layernorm(hs, n, V(ka + "ln.w"), V(ka + "ln.b"), TMP_LN_EPS, rows, Cc, 0, 0, V(ka + "pe"), hw, T));
+            const bool rope = h->cfg.pe_rope != 0;                   // motion_module.py:221-224: no additive encoding, q and k rotated instead
+            VDA_TRY(layernorm(hs, n, V(ka + "ln.w"), V(ka + "ln.b"), TMP_LN_EPS, rows, Cc, 0, 0, rope ? nullptr : V(ka + "pe"), hw, T));
             VDA_TRY(dense(n, W(ka + "qkv.w"), qkv, VDA_EPI_BIAS_F16, rows, 3 * Cc, Cc));
             for (int b = 0; b < B && !dry; ++b) {
                 const size_t r0 = (size_t)b * T * hw;
+                if (rope)
+                    VDA_TRY(prec == VDA_PREC_F32 ? vda_rope_qk_f32((float*)qkv + r0 * 3 * Cc, T, hw, Cc, s) : vda_rope_qk_f16((h16*)qkv + r0 * 3 * Cc, T, hw, Cc, s));
                 VDA_TRY(prec == VDA_PREC_F32
                             ? vda_temporal_attention_f32((const float*)qkv + r0 * 3 * Cc, (float*)ao + r0 * Cc, T, hw, Cc, TEMPORAL_HEADS, s)
                             : vda_temporal_attention_f16((const h16*)qkv + r0 * 3 * Cc, (h16*)ao + r0 * Cc, T, hw, Cc, TEMPORAL_HEADS, s));
@@ -880,6 +926,7 @@ extern "C" int vda_create(const vda_config* cfg, vda_model** out) {
                 "vda_create: embed_dim=%d must be num_heads=%d x 64 (the attention kernels are built for head dim 64)", cfg->embed_dim, cfg->num_heads);
     VDA_REQUIRE(cfg->depth > 0 && cfg->features > 0 && cfg->features % 64 == 0, "vda_create: depth=%d features=%d (features must be a multiple of 64)", cfg->depth, cfg->features);
     VDA_REQUIRE(cfg->num_frames > 0 && cfg->num_frames <= 32, "vda_create: num_frames=%d must be in 1..32", cfg->num_frames);
+    VDA_REQUIRE((cfg->use_clstoken | cfg->use_bn | cfg->pe_rope) >> 1 == 0, "vda_create: use_clstoken / use_bn / pe_rope are 0 or 1");
     for (int i = 0; i < 4; ++i) {
         VDA_REQUIRE(cfg->out_channels[i] > 0 && cfg->out_channels[i] % 8 == 0, "vda_create: out_channels[%d]=%d must be a positive multiple of 8", i, cfg->out_channels[i]);
         VDA_REQUIRE(cfg->taps[i] >= 0 && cfg->taps[i] < cfg->depth && (i == 0 || cfg->taps[i] > cfg->taps[i - 1]), "vda_create: taps must be increasing block indices below depth");

@@ -278,6 +278,53 @@ int tattn_valu_dispatch(const T* q, T* o, int Tn, int hw, int C, int heads, hipS
 
 static int g_tattn_variant = 1;   // 1: MFMA kernel for head dims 32/64/128; 0: VALU kernel everywhere (A/B, cross-check)
 
+// pe = 'rope' (motion_module.py:254-257): q and k of the fused projection rotated in place, channel pair (2i, 2i+1) by
+// frame * 10000^(-2i/C). A streaming pass over two thirds of qkv; one thread = 4 pairs (16 bytes of fp16) of q and the same of k.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) rope_qk_kernel(T* __restrict__ qkv, int Tn, int hw, int C) {
+    const int per_row = C / 8;                                  // 8-channel vectors per row of q (and of k)
+    const long long total = (long long)Tn * hw * per_row;
+    const float lnb = -9.210340371976184f / (float)C;           // -ln(10000) / C
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long row = i / per_row;
+        const int v = (int)(i - row * per_row);
+        const int t = (int)(row / hw);
+        float cs[4], sn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float freq = expf(lnb * (float)(2 * (v * 4 + e)));          // 1 / 10000^(2i / C), i = v*4 + e
+            sincosf((float)t * freq, &sn[e], &cs[e]);
+        }
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {                  // q, then k
+            T* p = qkv + row * 3 * C + part * C + v * 8;
+            float x[8], y[8];
+            load8(p, x);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[2 * e] = x[2 * e] * cs[e] - x[2 * e + 1] * sn[e];
+                y[2 * e + 1] = x[2 * e] * sn[e] + x[2 * e + 1] * cs[e];
+            }
+            store8(p, y);
+        }
+    }
+}
+template <typename T>
+int rope_launch(T* qkv, int Tn, int hw, int C, vda_stream_t stream) {
+    VDA_REQUIRE(qkv != nullptr && Tn > 0 && hw > 0 && C > 0 && C % 8 == 0, "vda_rope_qk: bad arguments (C=%d must be a multiple of 8)", C);
+    VDA_REQUIRE(((uintptr_t)qkv & 15) == 0, "vda_rope_qk: 16-byte alignment required");
+    const long long total = (long long)Tn * hw * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((rope_qk_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, qkv, Tn, hw, C);
+    VDA_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace
+
+extern "C" int vda_rope_qk_f16(void* qkv, int T, int hw, int C, vda_stream_t stream) { return rope_launch<h16>((h16*)qkv, T, hw, C, stream); }
+extern "C" int vda_rope_qk_f32(float* qkv, int T, int hw, int C, vda_stream_t stream) { return rope_launch<float>(qkv, T, hw, C, stream); }
+
 extern "C" int vda_temporal_attention_set_variant(int v) {
     g_tattn_variant = v;
     return 0;

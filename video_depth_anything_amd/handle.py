@@ -35,7 +35,8 @@ class ModelHandle:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         c = _lib.Config(cfg.embed_dim, cfg.depth, cfg.num_heads, (C.c_int32 * 4)(*cfg.taps), cfg.features,
-                        (C.c_int32 * 4)(*cfg.out_channels), cfg.num_frames, int(cfg.use_clstoken))
+                        (C.c_int32 * 4)(*cfg.out_channels), cfg.num_frames, int(cfg.use_clstoken), int(cfg.use_bn),
+                        int(cfg.pe == "rope"))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(lib.vda_create(C.byref(c), C.byref(h)), "vda_create")

@@ -194,6 +194,15 @@ def temporal_attention(qkv, out, T, hw, Cc, heads=8):
     check(fn(_p(qkv), _p(out), T, hw, Cc, heads, _stream(qkv)), "vda_temporal_attention")
 
 
+def rope_qk(qkv, T, hw, Cc):
+    """pe='rope': rotate the q and k thirds of qkv [T*hw, 3*C] in place (motion_module/attention.py:403-429)."""
+    _act(qkv, "qkv")
+    if qkv.numel() < T * hw * 3 * Cc:
+        raise ValueError("rope_qk buffer too small")
+    fn = lib.vda_rope_qk_f32 if qkv.dtype == F32 else lib.vda_rope_qk_f16
+    check(fn(_p(qkv), T, hw, Cc, _stream(qkv)), "vda_rope_qk")
+
+
 def bilinear_nhwc(x, out, B, h, w, H, W, Cc, add=None):
     _act(x, "x"), _req(out, x.dtype, "out"), _req(add, x.dtype, "add")
     fn = lib.vda_bilinear_nhwc_f32 if x.dtype == F32 else lib.vda_bilinear_nhwc_f16

@@ -37,11 +37,11 @@ class VideoDepthAnything:
     def __init__(self, encoder='vits', features=64, out_channels=[48, 96, 192, 384], use_bn=False, use_clstoken=False,
                  num_frames=32, pe='ape', **_unused):
         # num_block / out_channel / conv of the fork's constructor (video_depth.py:47-49) are accepted and unused, as there.
-        if use_bn or pe != 'ape':
-            raise NotImplementedError("use_bn=True and pe != 'ape' are not built (no released configuration uses them)")
         self.encoder = encoder
         self.intermediate_layer_idx = {'vits': [2, 5, 8, 11], 'vitl': [4, 11, 17, 23]}
-        self.cfg = get_config(encoder, features, out_channels, num_frames, use_clstoken)
+        # use_bn / pe='rope' (no released configuration sets them): BatchNorm folded into the fusion blocks' convs at pack time,
+        # rotary embedding of q / k in the temporal attention; any other pe raises NotImplementedError as motion_module.py:226-227
+        self.cfg = get_config(encoder, features, out_channels, num_frames, use_clstoken, use_bn, pe)
         self.engine = None
         self._device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self._sd = None
@@ -94,6 +94,9 @@ class VideoDepthAnything:
     def python_engine(self):
         """The Python launch sequence over the per-kernel ABI (engine.py): the bit-exact cross-check of the handle."""
         from .engine import Engine
+        if self.cfg.use_bn or self.cfg.pe != "ape":
+            raise NotImplementedError("the Python launch sequence (engine.py) covers the released configurations only; "
+                                      "use_bn / pe='rope' run through the handle (vda_forward)")
         e = Engine(self.cfg, self._ensure_engine().device)
         e.load_state_dict(self._sd, True)
         return e

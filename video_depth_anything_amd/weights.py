@@ -80,6 +80,14 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             for c in (1, 2):
                 s[f"{r}resConfUnit{u}.conv{c}.weight"] = (F_, F_, 3, 3)
                 s[f"{r}resConfUnit{u}.conv{c}.bias"] = (F_,)
+            if cfg.use_bn:                                   # util/blocks.py:60-62: nn.BatchNorm2d(features) x 2, registered after the convs
+                for c in (1, 2):
+                    b = f"{r}resConfUnit{u}.bn{c}."
+                    s[b + "weight"] = (F_,)
+                    s[b + "bias"] = (F_,)
+                    s[b + "running_mean"] = (F_,)
+                    s[b + "running_var"] = (F_,)
+                    s[b + "num_batches_tracked"] = ()
     s[sc + "output_conv1.weight"] = (F_ // 2, F_, 3, 3)
     s[sc + "output_conv1.bias"] = (F_ // 2,)
     s[sc + "output_conv2.0.weight"] = (32, F_ // 2, 3, 3)
@@ -100,7 +108,8 @@ def state_dict_spec(cfg: ModelConfig) -> "OrderedDict[str, Tuple[int, ...]]":
             s[ab + "to_v.weight"] = (C, C)
             s[ab + "to_out.0.weight"] = (C, C)
             s[ab + "to_out.0.bias"] = (C,)
-            s[ab + "pos_encoder.pe"] = (1, cfg.num_frames, C)
+            if cfg.pe == "ape":                              # (rope: freqs_cis is a plain attribute, motion_module.py:221-224 - no key)
+                s[ab + "pos_encoder.pe"] = (1, cfg.num_frames, C)
         for a in (0, 1):
             s[f"{tb}norms.{a}.weight"] = (C,)
             s[f"{tb}norms.{a}.bias"] = (C,)
@@ -148,6 +157,12 @@ def synthetic_state_dict(cfg: ModelConfig, seed: int = 0) -> "OrderedDict[str, t
         leaf = name.rsplit(".", 1)[-1]
         if name.endswith("pos_encoder.pe"):
             t = sinusoidal_pe(shape[1], shape[2])
+        elif leaf == "running_var":
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif leaf == "running_mean":
+            t = randn(shape, 0.2)
+        elif leaf == "num_batches_tracked":
+            t = torch.tensor(100, dtype=torch.int64)
         elif leaf == "gamma":
             t = 0.5 + 0.5 * torch.rand(shape, generator=g)
         elif name.endswith("cls_token") or name.endswith("mask_token"):
