@@ -244,6 +244,14 @@ int vda_head_out_f32_f32(const float* in, const float* w, float bias, float* out
 int vda_depth_tail_f16(const void* in, const void* w2, const float* b2, const float* w3, float b3, float* out,
                        const void* zero_page, int B, int h, int w, int H, int W, int C, vda_stream_t stream);
 
+/* output_conv1 applied to the 2x-upsampled output of refinenet1 (dpt.py:117 over util/blocks.py:156-160's
+ * F.interpolate(scale_factor=2, mode="bilinear", align_corners=True)) in one pass: NHWC fp16 in [B,h,w,C] ->
+ * out [B,2h,2w,ldc] = conv3x3(bilinear2x(in)) + bias, channels 0..N-1 written. w: fp16 [N, 9*C] with K ordered (ky,kx,ci)
+ * (the layout vda_gemm_f16's VDA_A_CONV3X3 takes); C a multiple of 16; N <= 128, N and ldc multiples of 4; bias fp32 [N] or NULL.
+ * The interpolated pixels are rounded to fp16 once, exactly as vda_bilinear_nhwc_f16 would have stored them. */
+int vda_conv3x3_up2_f16(const void* in, const void* w, const float* bias, void* out, int B, int h, int wd, int C, int N, int ldc,
+                        vda_stream_t stream);
+
 /* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
  * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */
 int vda_normalize_u8_f32(const uint8_t* frames, float* out, int n, int H, int W, vda_stream_t stream);
@@ -340,7 +348,9 @@ int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda
 int vda_debug_occupy(int wgs, int lds_bytes, long long cycles, vda_stream_t stream);
 /* Launch-sequence switches (A/B and cross-checks). "residual_in_ln" (default 0; fp16 path only): 1 = attn.proj / mlp.fc2 store
  * their output as fp16 and the residual add runs inside the following LayerNorm (vda_layernorm_residual_f32_f16); 0 = the add
- * is the GEMM's fp32 in-place epilogue (VDA_EPI_SCALE_RES_F32; measured 2 % faster end to end). Changes the workspace size. */
+ * is the GEMM's fp32 in-place epilogue (VDA_EPI_SCALE_RES_F32; measured 2 % faster end to end). Changes the workspace size.
+ * "ln_fold" (default 1), "dyn_sched" (default 0): csrc/host.hip. "oc1_fused" (default 1; fp16 path): refinenet1's 2x upsample is
+ * evaluated inside output_conv1 (vda_conv3x3_up2_f16) and path_1 never exists at full size; 0 = vda_bilinear_nhwc + the conv. */
 int vda_set_option(vda_model* h, const char* name, int value);
 /* Measurement hook (bench.py): from vda_profile_start until vda_profile_stop every `every`-th GEMM / conv launch of each
  * (shape, epilogue) inside vda_forward is bracketed by two events on the launch stream. vda_profile_stop waits for them and

@@ -904,3 +904,28 @@ def test_golden_tiny_with_bn_and_with_rope(golden_dir, name, kw, fp32):
         m.load_state_dict(synthetic_state_dict(get_config("tiny"), seed=1), strict=True)
     with pytest.raises(NotImplementedError):
         VideoDepthAnything(encoder="tiny", pe="alibi")
+
+
+@pytest.mark.parametrize("enc,fixture", [("tiny", "tiny_forward.npz"), ("vits", "vits_forward.npz")])
+def test_output_conv1_with_the_upsample_folded_in(golden_dir, enc, fixture):
+    """Default fp16 path: refinenet1's 2x upsample is evaluated inside output_conv1 (vda_conv3x3_up2_f16; dpt.py:117 over
+    util/blocks.py:156-160). Against the reference-generated golden with the fusion on and off; the two forms round the same
+    interpolated pixels to fp16 and differ by the conv's fp32 summation order only, so their depths agree far inside the tolerance."""
+    z = np.load(os.path.join(golden_dir, fixture))
+    m, cfg, _ = model_for(enc, int(z["sd_seed"]))
+    x = torch.from_numpy(z["x"]).cuda()
+    d1 = m.forward(x, fp32=False)
+    with pytest.raises(Exception):                       # path_1 does not exist at full size on this path ...
+        m.engine._check_stage_exists("p1")
+    t1 = m.engine.stage("path_1")[0].clone()             # ... stage() rebuilds it from the half-size buffer
+    m.engine.set_option("oc1_fused", 0)
+    d0 = m.forward(x, fp32=False)
+    t0 = m.engine.stage("path_1")[0]
+    m.engine.set_option("oc1_fused", 1)
+    assert torch.equal(t0, t1), "the half-size path_1, upsampled, is the unfused path's path_1"
+    key = "tiny.depth" if enc == "tiny" else "vits.nonsquare.depth"
+    check_map(f"{enc}.oc1_fused.depth", d1.cpu().numpy(), z["depth"], tol_of(key, False))
+    check_map(f"{enc}.oc1_unfused.depth", d0.cpu().numpy(), z["depth"], tol_of(key, False))
+    rel = float((d1 - d0).abs().mean() / d0.abs().mean())
+    assert rel < 1e-4, rel
+    assert torch.equal(m.forward(x, fp32=False), d1)

@@ -785,3 +785,34 @@ def test_rope_rotation_of_q_and_k(ops, T, hw, C, dtype):
     err = (out.double() - ref).abs().max().item()
     # fp32: sincosf / expf of an angle up to 31 rad; fp16: one rounding of the result (|x| < ~5 -> ulp 4e-3)
     assert err < (3e-5 if dtype == torch.float32 else 2.5e-3), err
+
+
+@pytest.mark.parametrize("B,h,w,Cin,Cout,ldc", [(2, 9, 11, 64, 32, 32), (1, 20, 37, 128, 64, 64), (2, 21, 19, 256, 128, 128), (1, 5, 3, 64, 24, 32),
+                                               (1, 40, 33, 64, 128, 128), (3, 16, 16, 32, 32, 64), (1, 1, 1, 64, 32, 32), (1, 148, 148, 64, 32, 32)])
+def test_conv3x3_over_fused_2x_upsample(ops, B, h, w, Cin, Cout, ldc):
+    """vda_conv3x3_up2_f16 = output_conv1 over refinenet1's upsample (dpt.py:117, util/blocks.py:156-160) in one kernel:
+    (a) against torch: interpolate(scale 2, bilinear, align_corners) in fp32, one rounding to fp16 (what the unfused path stores),
+    conv2d in fp32; (b) against the unfused HIP pair vda_bilinear_nhwc_f16 -> vda_gemm_f16(conv3x3) on the same operands: the two
+    differ by the fp32 summation order of the conv only."""
+    from video_depth_anything_amd import _lib
+    x = rnd(B, Cin, h, w, seed=301).to(F16)
+    wt, b = rnd(Cout, Cin, 3, 3, seed=302, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=303)
+    xin = dev(x.permute(0, 2, 3, 1).contiguous())
+    wp = dev(ops.pack_conv3x3(wt))
+    H, W_ = 2 * h, 2 * w
+    out = torch.full((B, H, W_, ldc), 7.0, dtype=F16, device="cuda")
+    ops.conv3x3_up2(xin, wp, dev(b), out, B, h, w, Cin, Cout, ldc)
+    up = F.interpolate(x.float(), size=(H, W_), mode="bilinear", align_corners=True).to(F16).float()
+    ref = F.conv2d(up, wt.to(F16).float(), b, padding=1).permute(0, 2, 3, 1)
+    close(out[..., :Cout], ref, what="conv3x3 over the fused upsample")
+    if ldc > Cout:
+        assert float((out[..., Cout:].float() - 7.0).abs().max()) == 0.0, "channels past N are not written"
+    if (9 * Cin) % 64:
+        return                                           # (the implicit GEMM wants K in whole 64-deep tiles)
+    upd = torch.empty(B, H, W_, Cin, dtype=F16, device="cuda")
+    ops.bilinear_nhwc(xin, upd, B, h, w, H, W_, Cin)
+    two = torch.empty(B, H, W_, Cout, dtype=F16, device="cuda")
+    ops.gemm(upd, wp, two, _lib.EPI_BIAS_F16, M=B * H * W_, N=Cout, K=9 * Cin, bias=dev(b), conv=(B, H, W_, Cin, H, W_, 1))
+    d = (out[..., :Cout].float() - two.float()).abs()
+    assert float(d.max()) <= 2.0 ** -9 * max(1.0, float(two.float().abs().max())), float(d.max())      # one fp16 ulp of the largest value
+    assert float((d > 0).float().mean()) < 0.12, "the fused and the unfused path agree bit for bit almost everywhere"

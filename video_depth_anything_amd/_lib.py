@@ -76,6 +76,7 @@ SIGNATURES = {
     "vda_readout_concat_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_head_out_f16_f32": (_i, [_vp, _vp, _f, _vp, _i, _i, _vp]),
     "vda_head_out_f32_f32": (_i, [_vp, _vp, _f, _vp, _ll, _i, _vp]),
+    "vda_conv3x3_up2_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_depth_tail_f16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "vda_normalize_u8_f32": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "vda_gather_normalize_u8_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -154,6 +154,7 @@ struct vda_model {
     int dyn_sched = 0;                        // vda_set_option("dyn_sched"): dynamic tile draw in the 8-phase GEMM (vda_gemm_args.sched); for
                                               // processes that share the GPU with communication kernels (multi-rank runs turn it on)
     int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
+    int oc1_fused = 1;                        // vda_set_option("oc1_fused"): refinenet1's 2x upsample folded into output_conv1 (fp16 path)
 };
 
 namespace {
@@ -657,7 +658,9 @@ struct Run {
         return 0;
     }
     // util/blocks.py:135-162 with out_conv moved in front of the (commuting) bilinear resize
-    int fusion(int i, const void* x0, const void* x1, int B, int H, int Wd, int Ho, int Wo, int Fe, const std::string& tag, void** result) {
+    // upsample = false: the caller's next conv does the resize itself (vda_conv3x3_up2_f16); *result is the out_conv output at H x Wd
+    int fusion(int i, const void* x0, const void* x1, int B, int H, int Wd, int Ho, int Wo, int Fe, const std::string& tag, void** result,
+               bool upsample = true) {
         const size_t rows = (size_t)B * H * Wd;
         const void* sm = x0;
         if (x1 != nullptr) {
@@ -667,9 +670,13 @@ struct Run {
         }
         void* r = act("fus_r", rows * Fe);
         VDA_TRY(rcu(i, 2, sm, r, B, H, Wd, Fe));
-        void* c = act("fus_c", rows * Fe);
+        void* c = act(upsample ? "fus_c" : tag, rows * Fe);
         const std::string k = "ref" + std::to_string(i) + ".out.";
         VDA_TRY(dense(r, W(k + "w"), c, VDA_EPI_BIAS_F16, (int)rows, Fe, Fe, V(k + "b")));
+        if (!upsample) {
+            *result = c;
+            return 0;
+        }
         void* out = act(tag, (size_t)B * Ho * Wo * Fe);
         VDA_TRY(bilinear(c, out, B, H, Wd, Ho, Wo, Fe));
         *result = out;
@@ -867,11 +874,17 @@ struct Run {
         VDA_TRY(fusion(3, p4t, l3r, BT, ph, pw, h2, w2, Fe, "p3", &p3));
         VDA_TRY(temporal(3, p3, B, T, h2 * w2, Fe, "p3t", &p3t));
         VDA_TRY(fusion(2, p3t, l2r, BT, h2, w2, h1, w1, Fe, "p2", &p2));
-        VDA_TRY(fusion(1, p2, l1r, BT, h1, w1, 2 * h1, 2 * w1, Fe, "p1", &p1));
+        // refinenet1's 2x upsample (util/blocks.py:156-160) is folded into output_conv1 on the fp16 path: path_1 at 8 ph x 8 pw (1.4 GB
+        // per ViT-L clip) never exists; "p1c" is refinenet1's out_conv output at 4 ph x 4 pw (bilinear and the 1x1 conv commute)
+        const bool up_fused = prec == VDA_PREC_F16 && h->oc1_fused != 0 && Fhp <= 128 && Fe % 16 == 0;
+        VDA_TRY(fusion(1, p2, l1r, BT, h1, w1, 2 * h1, 2 * w1, Fe, up_fused ? "p1c" : "p1", &p1, !up_fused));
         // ---- output convs (dpt.py:117-124, dpt_temporal.py:93-100)
         const int hh = 2 * h1, ww = 2 * w1;
         void* o1 = act("o1", (size_t)BT * hh * ww * Fhp);
-        VDA_TRY(conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, VDA_EPI_BIAS_F16, 1, V("oc1.b")));
+        if (up_fused) {
+            if (!dry) VDA_TRY(vda_conv3x3_up2_f16(p1, W("oc1.w"), V("oc1.b"), o1, BT, h1, w1, Fe, Fhp, Fhp, s));
+        } else
+            VDA_TRY(conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, VDA_EPI_BIAS_F16, 1, V("oc1.b")));
         if (prec == VDA_PREC_F16) {
             // bilinear to (H,W) + output_conv2 (3x3 -> ReLU -> 1x1 -> ReLU) fused: the upsampled tensor never exists
             if (!dry) VDA_TRY(vda_depth_tail_f16(o1, W("oc2.w"), V("oc2.b"), V("oc3.w"), h->oc3_bias, depth, h->zero_page, BT, hh, ww, H, Wd, Fhp, s));
@@ -1106,7 +1119,8 @@ static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_
     return 0;
 }
 
-// Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1), "dyn_sched" (default 0): see Run::forward.
+// Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1), "dyn_sched" (default 0), "oc1_fused"
+// (default 1): see Run::forward.
 extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     VDA_REQUIRE(h && name, "vda_set_option: null argument");
     if (strcmp(name, "residual_in_ln") == 0) {
@@ -1125,6 +1139,11 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     }
     if (strcmp(name, "ln_fold") == 0) {
         h->ln_fold = value;
+        h->layouts.clear();
+        return 0;
+    }
+    if (strcmp(name, "oc1_fused") == 0) {
+        h->oc1_fused = value;
         h->layouts.clear();
         return 0;
     }

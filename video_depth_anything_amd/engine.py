@@ -241,8 +241,8 @@ class Engine:
         self.conv3x3(x, f"ref{i}.rcu{u}.c1.w", y, B, H, W, Fe, Fe, _lib.EPI_BIAS_RELU_F16, bias=w[f"ref{i}.rcu{u}.c1.b"], relu_in=True)
         self.conv3x3(y, f"ref{i}.rcu{u}.c2.w", out, B, H, W, Fe, Fe, _lib.EPI_RES_F16, bias=w[f"ref{i}.rcu{u}.c2.b"], res=x, res2=res2)
 
-    def fusion(self, i, x0, x1, B, H, W, Ho, Wo, Fe, tag):
-        """util/blocks.py:135-162 with out_conv moved in front of the resize."""
+    def fusion(self, i, x0, x1, B, H, W, Ho, Wo, Fe, tag, upsample=True):
+        """util/blocks.py:135-162 with out_conv moved in front of the resize (upsample=False: the caller's conv resizes itself)."""
         w = self.w
         rows = B * H * W
         s = x0
@@ -251,8 +251,10 @@ class Engine:
             self.rcu(i, 1, x1, s, B, H, W, Fe, res2=x0)
         r = self.buf("fus_r", (rows, Fe), self.act)
         self.rcu(i, 2, s, r, B, H, W, Fe)
-        c = self.buf("fus_c", (rows, Fe), self.act)
+        c = self.buf("fus_c" if upsample else tag, (rows, Fe), self.act)
         ops.gemm(r, w[f"ref{i}.out.w"], c, _lib.EPI_BIAS_F16, M=rows, N=Fe, K=Fe, bias=w[f"ref{i}.out.b"])
+        if not upsample:
+            return c
         out = self.buf(tag, (B * Ho * Wo, Fe), self.act)
         ops.bilinear_nhwc(c, out, B, H, W, Ho, Wo, Fe)
         return out
@@ -387,12 +389,17 @@ class Engine:
         p3 = self.fusion(3, p4, l3r, BT, ph, pw, h2, w2, Fe, "p3")
         p3 = self.temporal(3, p3, B, T, h2 * w2, Fe, "p3t")
         p2 = self.fusion(2, p3, l2r, BT, h2, w2, h1, w1, Fe, "p2")
-        p1 = self.fusion(1, p2, l1r, BT, h1, w1, 2 * h1, 2 * w1, Fe, "p1")
+        # fp16 path: refinenet1's 2x upsample is folded into output_conv1 (vda_conv3x3_up2_f16), as csrc/host.hip does by default
+        up_fused = not fp32 and Fhp <= 128
+        p1 = self.fusion(1, p2, l1r, BT, h1, w1, 2 * h1, 2 * w1, Fe, "p1c" if up_fused else "p1", upsample=not up_fused)
 
         # ---- output convs (dpt.py:117-124, dpt_temporal.py:93-100)
         hh, ww = 2 * h1, 2 * w1
         o1 = self.buf("o1", (BT * hh * ww, Fhp), self.act)
-        self.conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, _lib.EPI_BIAS_F16, bias=w["oc1.b"])
+        if up_fused:
+            ops.conv3x3_up2(p1, w["oc1.w"], w["oc1.b"], o1, BT, h1, w1, Fe, Fhp, Fhp)
+        else:
+            self.conv3x3(p1, "oc1.w", o1, BT, hh, ww, Fe, Fhp, _lib.EPI_BIAS_F16, bias=w["oc1.b"])
         # bilinear to (H,W) + output_conv2 (3x3 -> ReLU -> 1x1 -> ReLU) in one kernel: the 518^2 x F/2 upsampled tensor is
         # never materialised (dpt_temporal.py:94-100)
         depth = torch.empty(B, T, H, W, dtype=F32, device=self.device)
@@ -409,5 +416,7 @@ class Engine:
         if stages is not None:
             stages.update(layer_1=(l1, h1, w1, ocp[0]), layer_2=(l2, h2, w2, ocp[1]), layer_3=(l3, ph, pw, ocp[2]),
                           layer_4=(l4, h4, w4, ocp[3]), path_4=(p4, ph, pw, Fe), path_3=(p3, h2, w2, Fe),
-                          path_2=(p2, h1, w1, Fe), path_1=(p1, hh, ww, Fe))
+                          path_2=(p2, h1, w1, Fe))
+            # (fused path: refinenet1's output before its 2x upsample)
+            stages.update(path_1_half=(p1, h1, w1, Fe)) if up_fused else stages.update(path_1=(p1, hh, ww, Fe))
         return depth

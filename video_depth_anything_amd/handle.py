@@ -133,8 +133,24 @@ class ModelHandle:
         t = torch.empty(BT * h * w, Cp, dtype=F32 if fp32 else F16, device=self.device)
         with torch.cuda.device(self.device):
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            _check(lib.vda_debug_copy(self._h, buf.encode(), C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), stream), "vda_debug_copy")
+            nbytes = t.numel() * t.element_size()
+            if name == "path_1" and lib.vda_debug_copy(self._h, b"p1", C.c_void_p(t.data_ptr()), nbytes, stream) != 0:
+                # default fp16 path: refinenet1's upsample is folded into output_conv1 (option "oc1_fused") and path_1 only exists
+                # at half size ("p1c"); what that conv interpolates on the fly is vda_bilinear_nhwc_f16 of it
+                from . import ops
+                half = torch.empty(BT * (h // 2) * (w // 2), Cp, dtype=t.dtype, device=self.device)
+                _check(lib.vda_debug_copy(self._h, b"p1c", C.c_void_p(half.data_ptr()), half.numel() * half.element_size(), stream), "vda_debug_copy")
+                ops.bilinear_nhwc(half, t, BT, h // 2, w // 2, h, w, Cp)
+            elif name != "path_1":
+                _check(lib.vda_debug_copy(self._h, buf.encode(), C.c_void_p(t.data_ptr()), nbytes, stream), "vda_debug_copy")
         return t, h, w, Cp
+
+    def _check_stage_exists(self, buf):
+        """Raises unless the last forward's workspace holds a buffer of that name (tests)."""
+        probe = torch.empty(16, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _check(lib.vda_debug_copy(self._h, buf.encode(), C.c_void_p(probe.data_ptr()), 16, stream), "vda_debug_copy")
 
     def set_option(self, name, value):
         _check(lib.vda_set_option(self._h, name.encode(), int(value)), "vda_set_option")

@@ -257,6 +257,17 @@ def depth_tail(x, w2, b2, w3, b3, out, B, h, w, H, W, Cc):
                                  _stream(x)), "vda_depth_tail_f16")
 
 
+def conv3x3_up2(x, w, bias, out, B, h, wd, Cc, N, ldc):
+    """out [B,2h,2w,ldc] = conv3x3(bilinear 2x, align_corners, of x [B,h,wd,C]) + bias: output_conv1 over refinenet1's upsample."""
+    _req(x, F16, "x"), _req(w, F16, "w"), _req(out, F16, "out")
+    if bias is not None:
+        _req(bias, F32, "bias")
+    if x.numel() < B * h * wd * Cc or out.numel() < B * 4 * h * wd * ldc or w.numel() < N * 9 * Cc:
+        raise ValueError("conv3x3_up2 buffers too small")
+    check(lib.vda_conv3x3_up2_f16(_p(x), _p(w), _p(bias) if bias is not None else None, _p(out), B, h, wd, Cc, N, ldc, _stream(x)),
+          "vda_conv3x3_up2_f16")
+
+
 def normalize_u8(frames, out, n, H, W):
     _req(frames, torch.uint8, "frames"), _req(out, F32, "out")
     check(lib.vda_normalize_u8_f32(_p(frames), _p(out), n, H, W, _stream(frames)), "vda_normalize_u8_f32")
