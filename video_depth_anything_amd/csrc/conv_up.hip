@@ -116,10 +116,10 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     // one (patch pixel, chunk) item: out = a00*(1-wx)(1-wy) + a01*wx(1-wy) + a10*(1-wx)wy + a11*wx*wy in fp32 (four v_fma_mix per
     // channel), one rounding to fp16. Branch-free: items past the patch write into its padding rows, pixels outside the image
     // write zeros (the conv's padding).
-    auto interp = [&](int k, const char* sb, char* pb) {
-        const h16x8 a00 = *reinterpret_cast<const h16x8*>(sb + (ia[k] & 0xffff)), a01 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)ia[k] >> 16));
-        const h16x8 a10 = *reinterpret_cast<const h16x8*>(sb + (ib[k] & 0xffff)), a11 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)ib[k] >> 16));
-        const float wx = wxs[k], wy = wys[k], ux = 1.f - wx, uy = 1.f - wy;
+    auto interp_item = [&](int k, int iav, int ibv, float wx, float wy, const char* sb, char* pb) {
+        const h16x8 a00 = *reinterpret_cast<const h16x8*>(sb + (iav & 0xffff)), a01 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)iav >> 16));
+        const h16x8 a10 = *reinterpret_cast<const h16x8*>(sb + (ibv & 0xffff)), a11 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)ibv >> 16));
+        const float ux = 1.f - wx, uy = 1.f - wy;
         const float w00 = ux * uy, w01 = wx * uy, w10 = ux * wy, w11 = wx * wy;
         h16x8 o;
 #pragma unroll
@@ -127,6 +127,11 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
         // items past the patch (the last 312 threads' third item) land in the patch buffer's 28 padding rows
         const int item = tid + NT * k, q = item < NITEM ? item >> 1 : NPIX + (lane & 15);
         *reinterpret_cast<h16x8*>(pb + lds_off(q, item & 1)) = o;
+    };
+    auto interp = [&](int k, const char* sb, char* pb) { interp_item(k, ia[k], ib[k], wxs[k], wys[k], sb, pb); };
+    // item ka in the early waves, item kb in the late ones (wave-uniform select between two register sets)
+    auto interp_sel = [&](bool early, int ka, int kb, const char* sb, char* pb) {
+        interp_item(early ? ka : kb, early ? ia[ka] : ia[kb], early ? ib[ka] : ib[kb], early ? wxs[ka] : wxs[kb], early ? wys[ka] : wys[kb], sb, pb);
     };
 
     f32x16 acc[2][CB];
@@ -150,67 +155,62 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     for (int k = 0; k < NI; ++k) interp(k, srcb, patch);
     __syncthreads();
 
-    // One k-step: the MFMAs of step j from patch[cur] / w[cur], and (INTERP) the patch of step j + 1 interpolated between them.
-    // Each kx group is one scheduling region: the next 32-cout block's weight fragments are requested before the running block's
-    // six MFMAs, and the interpolation's VALU work is dealt out two instructions per MFMA.
-    auto step = [&](int j, auto with_interp) {
-        constexpr bool INTERP = decltype(with_interp)::value;
-        const int cur = j & 1, nxt = cur ^ 1;
-        const char* const pc = patch + cur * PATCH_BYTES;
-        const char* const wc = wl + cur * W_BYTES;
+    // One k-step: the MFMAs of step j from patch[cur] / w[cur], and (INTERP) the patch of step j + 1 interpolated beside them.
+    // A kx group's 6 CB MFMAs are one scheduling region (the next 32-cout block's weight fragments are requested before the running
+    // block's six MFMAs). The three interpolation items sit BETWEEN the groups, one slot earlier in waves 0..3 than in waves 4..7
+    // (I M I M I M against M I M I M I): waves w and w + 4 share a SIMD, so one partner's VALU phase runs under the other's MFMAs.
+    const bool early = wave < 4;
+    auto mfma_group = [&](int kx, const char* pc, const char* wc) {
+        h16x8 P[4];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            h16x8 P[4];
+        for (int i = 0; i < 4; ++i) P[i] = *reinterpret_cast<const h16x8*>(pc + lds_off((wave * 2 + i) * PW + px + kx, hh));
+        h16x8 Wf[CB][3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) P[i] = *reinterpret_cast<const h16x8*>(pc + lds_off((wave * 2 + i) * PW + px + kx, hh));
-            h16x8 Wf[CB][3];
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+            for (int ky = 0; ky < 3; ++ky) Wf[cb][ky] = *reinterpret_cast<const h16x8*>(wc + lds_off(((ky * 3 + kx) * CB + cb) * 32 + px, hh));
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) Wf[cb][ky] = *reinterpret_cast<const h16x8*>(wc + lds_off(((ky * 3 + kx) * CB + cb) * 32 + px, hh));
-            if constexpr (INTERP) interp(kx, srcb + nxt * SRC_BYTES, patch + nxt * PATCH_BYTES);
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int r = 0; r < 2; ++r) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cb][ky], P[r + ky], acc[r][cb], 0, 0, 0);
+        // ---- the order the scheduler is asked for
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);                          // P + the first block's weights
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) acc[r][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wf[cb][ky], P[r + ky], acc[r][cb], 0, 0, 0);
-            // ---- the order the scheduler is asked for
-            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);                      // P + the first block's weights
-            if constexpr (CB == 1) {
-                if constexpr (INTERP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the four corners
-#pragma unroll
-                for (int m = 0; m < 6; ++m) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if constexpr (INTERP) __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                  // the second block's weights
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                  // first block
-                if constexpr (INTERP) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      // the four corners
-#pragma unroll
-                for (int cb = 1; cb < CB; ++cb) {
-                    if (cb + 1 < CB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);       // the next block's weights
-#pragma unroll
-                    for (int m = 0; m < 6; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if constexpr (INTERP) __builtin_amdgcn_sched_group_barrier(0x002, (54 + 6 * (CB - 1) - 1) / (6 * (CB - 1)), 0);
-                    }
-                }
-            }
-            if constexpr (INTERP) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);                                      // nothing moves across kx groups (register pressure)
+        for (int cb = 0; cb < CB; ++cb) {
+            if (cb + 1 < CB) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);     // the next block's weights
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);                                          // nothing moves across groups (register pressure)
     };
     for (int j = 0; j + 1 < nk; ++j) {
         // the barrier behind us published w[cur], patch[cur], src[nxt]; w[nxt], patch[nxt], src[cur] are free
         stage_w(j + 1, wl + ((j + 1) & 1) * W_BYTES);
         if (j + 2 < nk) stage_src(j + 2, srcb + (j & 1) * SRC_BYTES);
-        step(j, std::true_type{});
+        const int cur = j & 1, nxt = cur ^ 1;
+        const char* const pc = patch + cur * PATCH_BYTES;
+        const char* const wc = wl + cur * W_BYTES;
+        const char* const sb = srcb + nxt * SRC_BYTES;
+        char* const pb = patch + nxt * PATCH_BYTES;
+        if (early) interp(0, sb, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(0, pc, wc);
+        interp_sel(early, 1, 0, sb, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(1, pc, wc);
+        interp_sel(early, 2, 1, sb, pb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(2, pc, wc);
+        if (!early) interp(2, sb, pb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's LDS-DMA landed before the barrier publishes it
         __syncthreads();
     }
-    step(nk - 1, std::false_type{});
+    {
+        const int cur = (nk - 1) & 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) mfma_group(kx, patch + cur * PATCH_BYTES, wl + cur * W_BYTES);
+    }
     static_assert(NI == 3, "the interpolation items ride on the three kx groups");
 
     // ---- epilogue: lane = pixel (lane & 31) of row r; registers 4g..4g+3 of block cb = channels cb*32 + 8g + 4hh .. +3
