@@ -24,9 +24,10 @@ def ops():
     return o
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7, 9, 8, 5 + 16 * 64, 10], ids=["auto", "tile128", "tile256x256", "tile256x128", "tile256x256_mfma16", "tile256x128_mfma16",
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 7, 9, 8, 5 + 16 * 64, 10, 11], ids=["auto", "tile128", "tile256x256", "tile256x128", "tile256x256_mfma16", "tile256x128_mfma16",
                                                                             "tile256x256_8phase", "conv_lds_where_it_applies", "tile256x128_8phase", "tile192x128_6waves",
-                                                                            "tile192x256_8phase_where_built", "tile192x384_12waves_where_built"])
+                                                                            "tile192x256_8phase_where_built", "tile192x384_12waves_where_built",
+                                                                            "tile192x128_two_workgroups_per_cu_where_built"])
 def gemm_variant(request, ops):
     """Run every GEMM/conv test under each tile family (the dispatcher normally picks per shape)."""
     from video_depth_anything_amd._lib import lib

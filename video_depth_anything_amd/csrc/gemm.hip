@@ -217,6 +217,7 @@ int vda_gemm256s_dense_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn256(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_conv_bn128(const vda_gemm_args& a, hipStream_t s);
 int vda_gemm256s_dense_bn128_bm192(const vda_gemm_args& a, hipStream_t s);      // 192 x 128 tiles, six waves; -1 = epilogue not built
+int vda_gemm256s_dense_bn128_bm192_x2(const vda_gemm_args& a, hipStream_t s);   // the same tile, TWO workgroups per CU (variant 11); -1 = not built
 int vda_gemm256s_dense_bn384_bm192(const vda_gemm_args& a, hipStream_t s);      // 192 x 384 tiles, twelve waves; -1 = epilogue not built
 
 // gemm8p_*.hip: 256 x 256 tile, 8-phase two-group schedule
@@ -434,7 +435,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
     bool eight = g_gemm_variant >= 5 && (g_gemm_variant & 15) == 5;      // upper bits: A/B switches of the 8-phase kernel
     if (eight) big = 256;
     if (g_gemm_variant == 1 || g_gemm_variant == 3) big = 256;
-    if (g_gemm_variant == 2 || g_gemm_variant == 4 || g_gemm_variant == 8 || g_gemm_variant == 10) big = 128;
+    if (g_gemm_variant == 2 || g_gemm_variant == 4 || g_gemm_variant == 8 || g_gemm_variant == 10 || g_gemm_variant == 11) big = 128;
     if (g_gemm_variant == 1 || g_gemm_variant == 2) small_mfma = 0;
     if (g_gemm_variant == 9) {               // 9 = 256x128 8-phase two-group schedule
         eight = true;
@@ -520,6 +521,15 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
                 snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192>", a.a_mode, a.epilogue);
                 g_last_kernel = name384;
                 return rc384;
+            }
+        }
+        if (g_gemm_variant == 11 && a.a_mode == VDA_A_DENSE) {        // 192 x 128, two workgroups per CU (A/B only, see gemm256s_kernel.h)
+            const int rcx2 = vda_gemm256s_dense_bn128_bm192_x2(a8, s);
+            if (rcx2 >= 0) {
+                static thread_local char namex2[64];
+                snprintf(namex2, sizeof(namex2), "gemm256s_kernel<128, %d, %d, 192, 2>", a.a_mode, a.epilogue);
+                g_last_kernel = namex2;
+                return rcx2;
             }
         }
         if (tall192) {

@@ -2,3 +2,4 @@
 #include "gemm256s_kernel.h"
 
 int vda_gemm256s_dense_bn128_bm192(const vda_gemm_args& a, hipStream_t s) { return vda_gemm256s::launch_dense_bm192<128>(a, s); }
+int vda_gemm256s_dense_bn128_bm192_x2(const vda_gemm_args& a, hipStream_t s) { return vda_gemm256s::launch_dense_bm192_x2<128>(a, s); }

@@ -32,8 +32,13 @@ constexpr int ROW_BYTES = BK * 2;
 // ViT-S's whole embedding width, so proj / fc2 read their A panel and their residual rows once, and 43 840 rows are 229 tiles = one
 // round of the chip (687 tiles of 192 x 128 ran as 3). qkv (N = 1152) is three such column tiles. 144 KiB of pipeline buffers:
 // the epilogue stages through BOTH of them (12 x 8 KiB), so this variant issues the next tile's first K tile after its epilogue.
-template <int BN, int AMODE, int EPI, int BM = 256>
+// [r3] PER_CU = 2 (BM = 192, BN = 128 only): TWO such workgroups per CU, 80 KiB of LDS each (the epilogue stages through the pipeline
+// buffers and the next tile's first K tile is issued after it), twelve waves per CU = three per SIMD (<= 168 VGPRs). The two
+// workgroups of a CU drift out of phase, so one's epilogue runs under the other's K loop - the experiment VERDICT r2 item 2 asked for
+// (vda_gemm_set_variant(11)); measured against the 8-phase 256 x 256 kernel in DESIGN.md section 4.
+template <int BN, int AMODE, int EPI, int BM = 256, int PER_CU = 1>
 __global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kernel(const vda_gemm_args p) {
+    static_assert(PER_CU == 1 || (PER_CU == 2 && BM == 192 && BN == 128), "two workgroups per CU: the 192 x 128 tile only");
     static_assert(BM == 256 || (BM == 192 && (BN == 128 || BN == 384)), "tile heights: 256, or 192 with BN = 128 / 384");
     static_assert(BN != 384 || (BM == 192 && AMODE == VDA_A_DENSE), "384 columns: 192 rows, dense A");
     constexpr int NW = BN == 384 ? 12 : BM / 32;   // waves: 8, or 6, or 12
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kerne
     const int nt = p.K / BK;
     static_assert(WTN == 64, "epilogue staging assumes a 64-column wave tile");
     // epilogue staging (NW waves x 8 KiB): inside pipeline buffer 1 when that is 64 KiB (BN=256), else after the buffers
-    constexpr bool LATE_NEXT = NW * 8192 > STAGE && 2 * STAGE + NW * 8192 > 160 * 1024;   // staging needs both buffers (BN = 384)
+    constexpr bool LATE_NEXT = PER_CU == 2 || (NW * 8192 > STAGE && 2 * STAGE + NW * 8192 > 160 * 1024);   // staging needs both buffers (BN = 384)
     constexpr int STG_OFF = LATE_NEXT ? 0 : (STAGE >= 8 * 8192) ? STAGE : 2 * STAGE;
     char* stg = smem + STG_OFF + wave * 8192;
 
@@ -366,19 +371,24 @@ __global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kerne
     }
 }
 
-template <int BN, int AMODE, int EPI, int BM = 256>
+template <int BN, int AMODE, int EPI, int BM = 256, int PER_CU = 1>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int stage_bytes = (BM + BN) * ROW_BYTES;
     constexpr int nthreads = BN == 384 ? 768 : BM / 32 * 64;
-    constexpr int smem = (BN == 384 || stage_bytes >= 8 * 8192) ? 2 * stage_bytes : 2 * stage_bytes + BM / 32 * 8192;
-    static_assert(smem <= 160 * 1024, "LDS budget");
+    constexpr int smem = (PER_CU == 2 || BN == 384 || stage_bytes >= 8 * 8192) ? 2 * stage_bytes : 2 * stage_bytes + BM / 32 * 8192;
+    static_assert(smem * PER_CU <= 160 * 1024, "LDS budget");
     static VdaKernelDeviceState dev_state;
-    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI, BM>), smem, dev_state);
+    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm256s_kernel<BN, AMODE, EPI, BM, PER_CU>), smem, dev_state);
     if (num_cu < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
-    const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI, BM>), dim3(grid), dim3(nthreads), smem, s, a);
+    const int grid = ntiles < PER_CU * num_cu ? (ntiles + 7) / 8 * 8 : PER_CU * num_cu;     // PER_CU persistent workgroups per CU
+    if (PER_CU == 2 && getenv("VDA_DEBUG_OCC")) {           // what the runtime thinks fits on a CU (A/B aid)
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm256s_kernel<BN, AMODE, EPI, BM, PER_CU>, nthreads, smem);
+        fprintf(stderr, "gemm256s<%d,%d,%d,%d,2>: %d workgroups of %d threads, %d B LDS per CU (runtime occupancy query)\n", BN, AMODE, EPI, BM, nb, nthreads, smem);
+    }
+    hipLaunchKernelGGL((gemm256s_kernel<BN, AMODE, EPI, BM, PER_CU>), dim3(grid), dim3(nthreads), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
@@ -400,6 +410,19 @@ int launch_dense(const vda_gemm_args& a, hipStream_t s) {
         case VDA_EPI_SCALE_RES_SPLIT: return launch256<BN, VDA_A_DENSE, VDA_EPI_SCALE_RES_SPLIT>(a, s);
         case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16>(a, s);
         case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16>(a, s);
+        default: break;
+    }
+    return -1;
+}
+
+// two 192 x 128 workgroups per CU: the epilogues whose kernels fit 168 VGPRs (three waves per SIMD)
+template <int BN>
+int launch_dense_bm192_x2(const vda_gemm_args& a, hipStream_t s) {
+    switch (a.epilogue) {
+        case VDA_EPI_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_F16, 192, 2>(a, s);
+        case VDA_EPI_BIAS_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_BIAS_GELU_F16, 192, 2>(a, s);
+        case VDA_EPI_LN_BIAS_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_BIAS_F16, 192, 2>(a, s);
+        case VDA_EPI_LN_GELU_F16: return launch256<BN, VDA_A_DENSE, VDA_EPI_LN_GELU_F16, 192, 2>(a, s);
         default: break;
     }
     return -1;
