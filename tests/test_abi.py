@@ -64,3 +64,19 @@ def test_cpp_host_demo_builds_and_links(libpath):
     exe = build.build_host_demo()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "usage" in r.stderr
+
+
+def test_new_entry_points_refuse_bad_arguments_without_a_gpu(libpath):
+    """vda_conv3x3_up2_f16 / vda_rope_qk_f16 validate before any HIP call (null pointers, widths the kernels are not built for)."""
+    from video_depth_anything_amd import _lib
+    lib = _lib.lib
+    assert lib.vda_conv3x3_up2_f16(None, None, None, None, 1, 4, 4, 64, 32, 32, None) != 0
+    assert b"null" in lib.vda_last_error()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(ctypes.addressof(buf) + (-ctypes.addressof(buf)) % 16, ctypes.c_void_p)
+    assert lib.vda_conv3x3_up2_f16(p, p, None, p, 1, 4, 4, 24, 32, 32, None) != 0          # C not a multiple of 16
+    assert b"multiple of 16" in lib.vda_last_error()
+    assert lib.vda_conv3x3_up2_f16(p, p, None, p, 1, 4, 4, 64, 256, 256, None) != 0        # N > 128: the implicit GEMM's job
+    assert b"at most 128" in lib.vda_last_error()
+    assert lib.vda_rope_qk_f16(p, 4, 4, 12, None) != 0                                      # C not a multiple of 8
+    assert b"multiple of 8" in lib.vda_last_error()
