@@ -32,7 +32,7 @@ TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.n
          # round 3: the BENCHMARKED workloads at their own size: measured 9.2e-4 (ViT-S) / 2.0e-3 (ViT-L), bound = 2x. The reference's
          # OWN autocast-fp16 path (the oracle's torch ops on the GPU under torch.autocast, VDA_TEST_YARDSTICK=1) is 1.86e-3 / 4.5e-3
          # from the fp32 reference on the same clips: both bounds stay below it
-         "vits.32x518": 1.8e-3, "vitl.32x518": 4.0e-3,
+         "vits.32x518": 1.8e-3, "vitl.32x518": 4.0e-3, "vits.bn_rope.t32": 7.6e-3,
          # ... and the outlier-activation state dicts (tests/_outliers.py): see test_outlier_activations
          # (2x the larger of the two LayerNorm forms, measured: channels 4.0e-3 / 5.1e-3, offset 2.6e-3 / 3.2e-3, both 3.3e-3 / 4.1e-3 for
          # fold / standalone; the reference's OWN autocast-fp16 path on the same streams: 9.8e-3, 4.3e-2, 8.0e-3)
@@ -929,3 +929,30 @@ def test_output_conv1_with_the_upsample_folded_in(golden_dir, enc, fixture):
     rel = float((d1 - d0).abs().mean() / d0.abs().mean())
     assert rel < 1e-4, rel
     assert torch.equal(m.forward(x, fp32=False), d1)
+
+
+@pytest.mark.parametrize("fp32", PRECISIONS)
+def test_oracle_vits_with_bn_and_rope_32_frames(fp32):
+    """use_bn=True and pe='rope' TOGETHER at the released ViT-S widths and the full temporal length (T = 32: every frame's rotation
+    angle, head dims 8 / 24 / 48 of the temporal attention) on a small spatial grid, against the CPU oracle - which the
+    reference-generated tiny fixtures pin for both switches (tests/test_oracle_golden.py)."""
+    from oracle import vda_oracle as O
+    from video_depth_anything_amd.config import get_config
+    from video_depth_anything_amd.video_depth import VideoDepthAnything
+    from video_depth_anything_amd.weights import synthetic_state_dict
+    cfg = get_config("vits", use_bn=True, pe="rope")
+    sd = synthetic_state_dict(cfg, seed=21)
+    m = VideoDepthAnything(encoder="vits", features=cfg.features, out_channels=list(cfg.out_channels), use_bn=True, pe="rope")
+    m.load_state_dict(sd, strict=True)
+    m = m.to("cuda").eval()
+    x = torch.randn(1, 32, 3, 70, 98, generator=torch.Generator().manual_seed(22))
+    with torch.no_grad():
+        ref = oracle_once("vits.bn_rope.t32", lambda: O.forward(sd, cfg, x).numpy())
+    d = m.forward(x.cuda(), fp32=fp32).cpu().numpy()
+    e = check_map("vits.bn_rope.t32.depth_vs_oracle" + (".f32" if fp32 else ""), d, ref, tol_of("vits.bn_rope.t32", fp32))
+    if not fp32:
+        # (bound = 2x the first measurement, 3.8e-3: BatchNorm with random running statistics rescales channels by up to ~3x)
+        e16 = autocast_oracle_error(sd, cfg, x, ref)          # the reference's own fp16 path, when the yardstick run is on
+        if e16 is not None:
+            record("vits.bn_rope.t32.autocast_oracle_vs_fp32", e16)
+            assert e is None or e < 1.5 * e16 + 5e-4

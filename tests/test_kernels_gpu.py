@@ -817,3 +817,32 @@ def test_conv3x3_over_fused_2x_upsample(ops, B, h, w, Cin, Cout, ldc):
     d = (out[..., :Cout].float() - two.float()).abs()
     assert float(d.max()) <= 2.0 ** -9 * max(1.0, float(two.float().abs().max())), float(d.max())      # one fp16 ulp of the largest value
     assert float((d > 0).float().mean()) < 0.12, "the fused and the unfused path agree bit for bit almost everywhere"
+
+
+def test_conv3x3_fused_upsample_at_the_benchmarked_grid(ops):
+    """ViT-L's output_conv1 as the benchmark runs it (32 frames of 148^2 -> 296^2, 256 -> 128 channels: 6080 workgroups, 359 M
+    output elements): the fused kernel against the unfused HIP pair at every output (one fp16 ulp; the pair itself is checked
+    against torch in test_bilinear_nhwc / test_conv3x3), and against torch's fp32 arithmetic on two sampled frames."""
+    from video_depth_anything_amd import _lib
+    B, h, C, N = 32, 148, 256, 128
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, h, h, C, generator=g).to(F16)
+    wt, b = torch.randn(N, C, 3, 3, generator=g) * (9 * C) ** -0.5, torch.randn(N, generator=g)
+    xin, wp, bd = x.cuda(), dev(ops.pack_conv3x3(wt)), b.cuda()
+    H = 2 * h
+    out = torch.empty(B, H, H, N, dtype=F16, device="cuda")
+    ops.conv3x3_up2(xin, wp, bd, out, B, h, h, C, N, N)
+    up = torch.empty(B, H, H, C, dtype=F16, device="cuda")
+    ops.bilinear_nhwc(xin, up, B, h, h, H, H, C)
+    two = torch.empty(B, H, H, N, dtype=F16, device="cuda")
+    ops.gemm(up, wp, two, _lib.EPI_BIAS_F16, M=B * H * H, N=N, K=9 * C, bias=bd, conv=(B, H, H, C, H, H, 1))
+    dmax, frac = 0.0, 0.0
+    for f in range(B):                                   # frame by frame: the fp32 difference of 359 M elements would be 1.4 GB
+        d = (out[f].float() - two[f].float()).abs()
+        dmax, frac = max(dmax, float(d.max())), frac + float((d > 0).float().mean()) / B
+    assert dmax <= 2.0 ** -9 * max(1.0, float(two.float().abs().max())), dmax
+    assert frac < 0.12, frac
+    for f in (0, B - 1):
+        upf = F.interpolate(x[f:f + 1].permute(0, 3, 1, 2).float(), size=(H, H), mode="bilinear", align_corners=True).to(F16).float()
+        ref = F.conv2d(upf, wt.to(F16).float(), b, padding=1).permute(0, 2, 3, 1)
+        close(out[f:f + 1], ref, what=f"fused output_conv1, frame {f}")
