@@ -32,7 +32,7 @@ TOL16 = {"tiny.tap": 1.3e-3, "tiny.stage": 2.4e-3, "tiny.depth": 1.8e-3, "vits.n
          # round 3: the BENCHMARKED workloads at their own size: measured 9.2e-4 (ViT-S) / 2.0e-3 (ViT-L), bound = 2x. The reference's
          # OWN autocast-fp16 path (the oracle's torch ops on the GPU under torch.autocast, VDA_TEST_YARDSTICK=1) is 1.86e-3 / 4.5e-3
          # from the fp32 reference on the same clips: both bounds stay below it
-         "vits.32x518": 1.8e-3, "vitl.32x518": 4.0e-3, "vits.bn_rope.t32": 7.6e-3,
+         "vits.32x518": 1.8e-3, "vitl.32x518": 4.0e-3, "vits.bn_rope.t32": 7.6e-3, "video.ragged": 8.4e-3,
          # ... and the outlier-activation state dicts (tests/_outliers.py): see test_outlier_activations
          # (2x the larger of the two LayerNorm forms, measured: channels 4.0e-3 / 5.1e-3, offset 2.6e-3 / 3.2e-3, both 3.3e-3 / 4.1e-3 for
          # fold / standalone; the reference's OWN autocast-fp16 path on the same streams: 9.8e-3, 4.3e-2, 8.0e-3)
@@ -956,3 +956,19 @@ def test_oracle_vits_with_bn_and_rope_32_frames(fp32):
         if e16 is not None:
             record("vits.bn_rope.t32.autocast_oracle_vs_fp32", e16)
             assert e is None or e < 1.5 * e16 + 5e-4
+
+
+@pytest.mark.parametrize("n_frames", [1, 5, 31, 32, 33, 54, 55])
+def test_short_and_ragged_videos_against_the_oracle(n_frames):
+    """The sliding window's edge cases (video_depth.py:166-254): a single frame, fewer frames than one window (the last frame is
+    repeated to fill it), exactly one window, one frame into the second window, and the 54 / 55 boundary where a third window
+    appears - infer_video_depth in the fp32 path against the oracle's, tiny model (the stitch amplifies nothing in fp32)."""
+    from oracle import vda_oracle as O
+    m, cfg, sd = model_for("tiny", 3)
+    frames = np.random.default_rng(100 + n_frames).integers(0, 256, (n_frames, 28, 42, 3), dtype=np.uint8)
+    ref = O.infer_video_depth(sd, cfg, frames, 24, input_size=28)[0]
+    d, fps = m.infer_video_depth(frames, 24, input_size=28, device="cuda", fp32=True)
+    assert d.shape == ref.shape == (n_frames, 28, 42) and d.dtype == np.float32 and fps == 24
+    check_map(f"video.ragged.n{n_frames}.f32", d, ref, TOL32, tail=False)
+    d16, _ = m.infer_video_depth(frames, 24, input_size=28, device="cuda", fp32=False)
+    check_map(f"video.ragged.n{n_frames}", d16, ref, TOL16["video.ragged"], tail=False)      # 2x the largest measured (n = 1: 4.2e-3, a 2 x 3 token grid)
