@@ -119,7 +119,9 @@ int vda_gemm_set_variant(int v);
  * advance A / out / res / res2 / out2 by M1 rows, stats (VDA_EPI_LN_*) and pos (VDA_EPI_SCALE_RES_SPLIT) by M1 rows of 2 floats,
  * stats (VDA_EPI_SCALE_RES_SPLIT) by M1 rows of 2 floats with stats_ld = M. A row's result is bit-identical either way. */
 int vda_gemm_plan_split(int M, int N, int K, int epilogue, int a_mode);
-/* *out = the arguments of rows [r0, r0 + rows) of *args by exactly those rules (lda / ldc of 0 resolved to K / N first). */
+/* *out = the arguments of rows [r0, r0 + rows) of *args by exactly those rules. lda / ldc of 0 are read as K / N HERE (a row range
+ * is of a real matrix); vda_gemm_f16 itself reads lda == 0 as "every row is A's row 0" (broadcast) and never row-splits such a
+ * call on its own. Any kernel family honours stats_ld (the 8-phase, one-barrier and 128-row kernels alike). */
 int vda_gemm_row_range(const vda_gemm_args* args, int r0, int rows, vda_gemm_args* out);
 /* Name of the kernel family the last vda_gemm_f16 call on this thread dispatched to (for profiling reports). */
 const char* vda_gemm_last_kernel(void);

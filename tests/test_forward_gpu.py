@@ -787,14 +787,18 @@ def test_memory_mapped_video_equals_in_memory_video(tmp_path):
 
 def test_frames_that_are_not_uint8():
     """The reference divides whatever array it is handed by 255 (video_depth.py:198); the device path keeps the video as uint8,
-    so integer arrays holding 8-bit values are converted (same arithmetic) and anything else is refused, never truncated."""
+    so arrays of any dtype holding 8-bit integer values are converted (same arithmetic) and anything else is refused, never truncated."""
     m, _, _ = model_for("tiny", 6)
     frames = np.random.default_rng(35).integers(0, 256, (12, 28, 42, 3), dtype=np.uint8)
     a, _ = m.infer_video_depth(frames, 24, input_size=28, device="cuda")
     b, _ = m.infer_video_depth(frames.astype(np.int64), 24, input_size=28, device="cuda")
     assert np.array_equal(a, b)
+    c, _ = m.infer_video_depth(frames.astype(np.float32), 24, input_size=28, device="cuda")     # float frames holding 0..255 integers
+    assert np.array_equal(a, c)
     with pytest.raises(TypeError, match="8-bit"):
         m.infer_video_depth(frames.astype(np.float32) / 255.0, 24, input_size=28, device="cuda")
+    with pytest.raises(TypeError, match="8-bit"):
+        m.infer_video_depth(frames.astype(np.float32) + 0.5, 24, input_size=28, device="cuda")
     with pytest.raises(TypeError, match="8-bit"):
         m.infer_video_depth(frames.astype(np.int32) * 2, 24, input_size=28, device="cuda")
     with pytest.raises(ValueError, match=r"\[N, H, W, 3\]"):

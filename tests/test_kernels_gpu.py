@@ -406,6 +406,76 @@ def test_gemm_row_split_is_bit_identical(ops, epi_name):
         assert torch.isfinite(x).all() and torch.equal(x, y), f"{epi_name} output {t}: {int((x != y).sum())} elements differ between the split and the single launch"
 
 
+def test_gemm_split_residual_without_recentring_survives_the_row_split(ops):
+    """VDA_EPI_SCALE_RES_SPLIT with pos == NULL at a shape the dispatcher row-splits (fc2's). The first pass points pos at
+    the 256-byte zero page with stride 0; the two row-range calls must keep that stride (they used to come back as "pos given",
+    stride 2, and read 43 840 rows of (mean, rstd) out of a 256-byte page). Bit-identical to the single 8-phase launch."""
+    from video_depth_anything_amd import _lib
+    lib = _lib.lib
+    M, N, K = 43840, 1024, 4096
+    epi = _lib.EPI_SCALE_RES_SPLIT
+    assert lib.vda_gemm_plan_split(M, N, K, epi, _lib.A_DENSE) < M
+    A, W, b = dev(rnd(M, K, seed=210).to(F16)), dev(rnd(N, K, seed=211, scale=K ** -0.5).to(F16)), dev(rnd(N, seed=212))
+    gamma = dev(rnd(N, seed=213).abs() + 0.5)
+    x = rnd(M, N, seed=214, scale=2.0)
+    guard = torch.full((1 << 20,), 1.0e4, device="cuda")     # whatever lies behind the zero page must not matter either
+
+    def run(variant):
+        lib.vda_gemm_set_variant(variant)
+        try:
+            hi, lo = dev(x.to(F16)), dev((x - x.to(F16).float()).to(F16))
+            part = torch.full((N // 64, M, 2), float("nan"), device="cuda")
+            ops.gemm(A, W, hi, epi, M=M, N=N, K=K, bias=b, gamma=gamma, res=hi, res2=lo, out2=lo, stats=part)      # no pos
+            return hi, lo, part
+        finally:
+            lib.vda_gemm_set_variant(-1)
+
+    split, single = run(-1), run(5)
+    del guard
+    for t, (u, v) in enumerate(zip(split, single)):
+        assert torch.isfinite(u).all() and torch.equal(u, v), f"output {t}: {int((u != v).sum())} elements differ"
+    # and against the definition on sampled rows: x' = x + gamma * (A W^T + b), no re-centring
+    sel = torch.arange(0, M, 97)
+    ref = x[sel] + gamma.cpu() * (A[sel.cuda()].float().cpu() @ W.float().cpu().t() + b.cpu())
+    got = split[0][sel.cuda()].float().cpu() + split[1][sel.cuda()].float().cpu()
+    assert (got - ref).abs().max() < 2e-2 and ((got - ref).abs().mean() / ref.abs().mean()) < 5e-4
+
+
+@pytest.mark.parametrize("variant", [0, 3, 4, 5])
+def test_gemm_row_range_statistics_layout_under_every_kernel_family(ops, variant):
+    """a row range of a split-residual GEMM (pointers advanced, M = rows of the range, stats_ld = rows of the WHOLE GEMM)
+    must write its partial statistics into the [N/64, stats_ld, 2] array whichever kernel family the dispatcher lands on: the
+    128-row kernel + split_partials pass (0), the one-barrier 256 x 256 / 256 x 128 kernels (3 / 4) and the 8-phase kernel (5).
+    Two ranges of one GEMM == the single launch under the same variant, bit for bit, planes and statistics."""
+    import ctypes as C
+    from video_depth_anything_amd import _lib
+    lib = _lib.lib
+    M, N, K = 4608, 512, 256
+    m1 = 2560
+    epi = _lib.EPI_SCALE_RES_SPLIT
+    A, W, b = dev(rnd(M, K, seed=220).to(F16)), dev(rnd(N, K, seed=221, scale=K ** -0.5).to(F16)), dev(rnd(N, seed=222))
+    gamma = dev(rnd(N, seed=223).abs() + 0.5)
+    x = rnd(M, N, seed=224, scale=2.0)
+    stat = dev(torch.stack([rnd(M, seed=225) * 0.1, torch.ones(M)], dim=1).contiguous())
+
+    def planes():
+        return dev(x.to(F16)), dev((x - x.to(F16).float()).to(F16)), torch.full((N // 64, M, 2), float("nan"), device="cuda")
+
+    lib.vda_gemm_set_variant(variant)
+    try:
+        hi, lo, part = planes()
+        ops.gemm(A, W, hi, epi, M=M, N=N, K=K, bias=b, gamma=gamma, res=hi, res2=lo, out2=lo, stats=part, pos=stat)
+        hi2, lo2, part2 = planes()
+        for r0, rows in ((0, m1), (m1, M - m1)):
+            ops.gemm(A[r0:], W, hi2[r0:], epi, M=rows, N=N, K=K, bias=b, gamma=gamma, res=hi2[r0:], res2=lo2[r0:], out2=lo2[r0:],
+                     stats=part2[0, r0:], pos=stat[r0:], stats_ld=M)
+    finally:
+        lib.vda_gemm_set_variant(-1)
+    assert torch.isfinite(part).all() and torch.isfinite(part2).all(), "unwritten partial statistics"
+    for name, u, v in (("hi", hi2, hi), ("lo", lo2, lo), ("partials", part2, part)):
+        assert torch.equal(u, v), f"variant {variant} {name}: {int((u != v).sum())} elements differ between two row ranges and one launch"
+
+
 def test_gemm_dynamic_tile_schedule_is_result_neutral(ops):
     """vda_gemm_args.sched (eight zeroed counters: the 8-phase kernel draws its tiles dynamically) changes which workgroup computes
     which tile, never a result - also when another kernel holds part of the GPU while it runs."""

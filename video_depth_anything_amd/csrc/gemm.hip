@@ -185,7 +185,7 @@ int launch(const vda_gemm_args& a, hipStream_t s) {
 // Partial row statistics of the split stream for the kernels whose epilogue is not row-layout (small problems only):
 // part[j, m, :] = (sum, centred sum of squares) of hi + lo over columns 64j..64j+63, one lane per (row, 64-column block).
 __global__ void __launch_bounds__(256) split_partials_kernel(const h16* __restrict__ hi, const h16* __restrict__ lo, float* __restrict__ part,
-                                                             int M, int N, int ldc) {
+                                                             int M, int N, int ldc, int ld) {
     const int np = N >> 6;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)M * np) return;
@@ -200,8 +200,8 @@ __global__ void __launch_bounds__(256) split_partials_kernel(const h16* __restri
         const float d = ((float)a[e] + (float)b[e]) - mean;
         sq = fmaf(d, d, sq);
     }
-    part[2 * ((size_t)j * M + m)] = sum;
-    part[2 * ((size_t)j * M + m) + 1] = sq;
+    part[2 * ((size_t)j * ld + m)] = sum;             // ld = rows per column block of the array (stats_ld: M of the WHOLE GEMM for a row range)
+    part[2 * ((size_t)j * ld + m) + 1] = sq;
 }
 
 }  // namespace
@@ -250,7 +250,7 @@ static int launch_small(const vda_gemm_args& a, hipStream_t s) {
             // this kernel's epilogue does not own whole row segments: the partial statistics come from a pass over the planes
             const long long items = (long long)a.M * (a.N >> 6);
             hipLaunchKernelGGL(split_partials_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, (const h16*)a.out, (const h16*)a.out2, a.stats, a.M,
-                               a.N, a.ldc);
+                               a.N, a.ldc, a.stats_ld ? a.stats_ld : a.M);
             VDA_LAUNCH_CHECK();
         }
         return rc;
@@ -317,8 +317,8 @@ extern "C" int vda_gemm_plan_split(int M, int N, int K, int epilogue, int a_mode
 // args of the row range [r0, r0 + rows) of a dense GEMM (the layout rules of vda_gemm_plan_split's comment in vda.h)
 static vda_gemm_args row_range(const vda_gemm_args& a0, int r0, int rows) {
     vda_gemm_args a = a0;
-    if (a.lda == 0) a.lda = a.K;
-    if (a.ldc == 0) a.ldc = a.N;
+    if (a.lda == 0) a.lda = a.K;       // vda.h: the public row-range helper reads 0 as "dense, K" (vda_gemm_f16 itself reads lda == 0 as a
+    if (a.ldc == 0) a.ldc = a.N;       // broadcast row and therefore never row-splits such a GEMM on its own: see the guard at its split)
     vda_gemm_args p = a;
     auto adv = [&](const void* q, size_t bytes_per_row) -> const void* { return q ? (const char*)q + (size_t)r0 * bytes_per_row : nullptr; };
     const bool f32_out = a.epilogue == VDA_EPI_SCALE_RES_F32;
@@ -390,7 +390,8 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
             VDA_REQUIRE(((uintptr_t)a.res & 15) == 0 && ((uintptr_t)a.res2 & 15) == 0 && ((uintptr_t)a.out2 & 15) == 0 && ((uintptr_t)a.stats & 7) == 0,
                         "vda_gemm_f16: split-residual planes must be 16-byte aligned");
             // re-centring rows (pos = [M, 2] (mean, rstd), optional): the kernels load pos[m * P] unconditionally
-            if (a.pos != nullptr) {
+            // (pos == zero_page is this function's own "no re-centring" form coming back through the row split below: stride 0 stays)
+            if (a.pos != nullptr && (const void*)a.pos != a.zero_page) {
                 VDA_REQUIRE(((uintptr_t)a.pos & 7) == 0, "vda_gemm_f16: pos (re-centring statistics) must be 8-byte aligned");
                 a.P = 2;
             } else {
@@ -487,7 +488,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
         }
         // Row split (vda_gemm_plan_split): whole rounds of 256-row tiles + one launch of 192-row tiles for the remainder. Applied here
         // when the caller left it to the dispatcher (no per-launch sched counters: those belong to ONE launch).
-        if (eight && big == 256 && a.a_mode == VDA_A_DENSE && g_gemm_variant < 0 && may_split && a.tile_rows == 0 && a.sched == nullptr) {
+        if (eight && big == 256 && a.a_mode == VDA_A_DENSE && g_gemm_variant < 0 && may_split && a.tile_rows == 0 && a.sched == nullptr && a.lda != 0) {
             const int m1 = vda_gemm_plan_split(a.M, a.N, a.K, a.epilogue, a.a_mode);
             if (m1 < a.M) {
                 vda_gemm_args p1 = row_range(a, 0, m1), p2 = row_range(a, m1, a.M - m1);

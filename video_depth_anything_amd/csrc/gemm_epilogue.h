@@ -225,7 +225,7 @@ struct RowAux {
 
 // [column block][row] layout of the partial statistics: the 8 rows a wave instruction covers are one 64-byte run
 __device__ __forceinline__ void store_split_stats(const vda_gemm_args& p, int m, int n, const RowAux& x) {
-    *reinterpret_cast<float2*>(p.stats + ((size_t)(n >> 6) * p.M + m) * 2) = float2{x.o0, x.o1};
+    *reinterpret_cast<float2*>(p.stats + ((size_t)(n >> 6) * (p.stats_ld ? p.stats_ld : p.M) + m) * 2) = float2{x.o0, x.o1};   // (stats_ld: a row range of a larger GEMM)
 }
 
 // GUARD = false: the caller has established that every row / column of the wave's tile is inside the matrix. The bounds

@@ -82,7 +82,7 @@ def zero_page(device):
 
 
 def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, res2=None, gamma=None, pos=None,
-         relu_in=False, conv=None, P=0, convt=None, out2=None, stats=None, sched=None):
+         relu_in=False, conv=None, P=0, convt=None, out2=None, stats=None, sched=None, stats_ld=0, tile_rows=0):
     """out = epilogue(A[M,K] W[N,K]^T). conv = (B,H,W,Cin,Ho,Wo,stride) switches A to the
     implicit 3x3 window of an NHWC tensor; convt = (k, h, w, Cout) for VDA_EPI_CONVT_F16."""
     _act(A, "A"), _req(W, A.dtype, "W"), _req(bias, F32, "bias"), _req(gamma, F32, "gamma"), _req(pos, F32, "pos")
@@ -102,6 +102,7 @@ def gemm(A, W, out, epi, *, M, N, K, lda=None, ldc=None, bias=None, res=None, re
     if conv is not None:
         a.cB, a.cH, a.cW, a.cCin, a.cHo, a.cWo, a.cStride = conv
     a.P = P
+    a.stats_ld, a.tile_rows = stats_ld, tile_rows      # a row range of a larger GEMM (vda_gemm_row_range's rules)
     if convt is not None:
         a.tK, a.tH, a.tW, a.tCout = convt
     if W.numel() < N * K:

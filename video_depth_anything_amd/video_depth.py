@@ -129,12 +129,19 @@ class VideoDepthAnything:
             raise ValueError("infer_video_depth: frames must be [N, H, W, 3], got shape %r" % (tuple(frames.shape),))
         if frames.dtype != np.uint8:
             # The reference computes frame.astype(float32) / 255 on whatever it is handed (video_depth.py:198). The device path
-            # keeps the video as uint8 in HBM, which is the same arithmetic exactly when the values ARE 0..255 integers: other
-            # integer dtypes holding such values are converted, anything else (float frames, wider ranges) is refused rather
-            # than silently truncated.
-            if not np.issubdtype(frames.dtype, np.integer) or frames.min() < 0 or frames.max() > 255:
-                raise TypeError("infer_video_depth: frames must hold 8-bit values (uint8, or an integer array within 0..255); got dtype %s"
-                                % frames.dtype)
+            # keeps the video as uint8 in HBM, which is the same arithmetic exactly when the values ARE 0..255 integers: arrays of
+            # any dtype holding such values (wider integers, float32 frames out of a cv2 pipeline) are converted; values that are
+            # not 8-bit (fractions, negatives, > 255, NaN) are refused rather than silently truncated.
+            ok = True
+            for i in range(0, frames.shape[0], 64):              # chunked: a memory-mapped video is not paged in at once
+                c = np.asarray(frames[i:i + 64])
+                ok = bool(c.size == 0 or (c.min() >= 0 and c.max() <= 255 and
+                                          (np.issubdtype(c.dtype, np.integer) or np.array_equal(c, np.rint(c)))))
+                if not ok:
+                    break
+            if not ok:
+                raise TypeError("infer_video_depth: frames must hold 8-bit values (uint8, or any dtype whose values are integers "
+                                "within 0..255); got dtype %s with other values" % frames.dtype)
             frames = frames.astype(np.uint8)
         H0, W0 = frames.shape[1:3]
         H, W = network_size(H0, W0, input_size)
