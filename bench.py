@@ -2,9 +2,13 @@
 """Headline benchmark: frames/s of VideoDepthAnything.forward on synthetic 1x32x518x518, ViT-L, fp16
 operands (BASELINE.json metric / configs[2]), on N MI355X of one node.
 
-  python bench.py [--gpus N --steps K --warmup W] [--encoder vitl|vits]
+  python bench.py [--gpus N --steps K --warmup W] [--encoder vitl|vits] [--video N_FRAMES]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
+          (a bare `python bench.py --gpus N` starts exactly that command as a CHILD process and relays its one JSON line)
+  --video N_FRAMES: BASELINE.json configs[3] - infer_video_depth over N synthetic 518x518 uint8 frames (sliding windows sharded
+          over the ranks, one all-gather per round to stitch, result on rank 0); `value` = OUTPUT frames/s, host uint8 in ->
+          host fp32 out (the API's boundary: PCIe-inclusive, stitch included).
 
 A step = one forward pass over one 32-frame clip (one sliding window) per rank, input resident in HBM.
 Windows are independent units: ranks shard them with no data-path collective; for N > 1
@@ -104,6 +108,87 @@ def cpu_baseline(encoder, full=True):
                       f"{dt:.1f} s per rep, {cores} threads (fastest of a probe over 8..{limit}; host has {limit} usable physical cores)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start `python -m torch.distributed.run ... bench.py <same args>` as a
+    CHILD process (never an exec of this one) and relay its output; this parent makes no GPU call at all. Returns the child's
+    exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    print(f"[bench] --gpus {n} without a launcher: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                          # relay (rank 0's one JSON line among it)
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
+def video_bench(args, model, dist, backend, world, rank, dev):
+    """BASELINE.json configs[3] / SURVEY.md section 8(d): infer_video_depth (video_depth.py:166-254) over N synthetic 518x518 frames.
+    Windows are sharded round-robin over the ranks with no data-path collective; one all-gather per round delivers the windows to
+    the stitcher (rank 0 returns the video, the other ranks return None). A step = one pass over the whole video."""
+    import numpy as np
+    from video_depth_anything_amd.scheduler import plan_windows
+    n = args.video
+    frames = np.random.default_rng(0).integers(0, 256, (n, 518, 518, 3), dtype=np.uint8)      # SURVEY 8(d): the same video on every rank
+    model.result_ranks = (0,)
+    model.exchange = args.exchange
+    warm = frames[:min(n, 76)]                          # 4 windows: allocations, first-touch, both lanes
+    for _ in range(max(args.warmup, 1)):
+        model.infer_video_depth(warm, 24, fp32=args.fp32)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out, _ = model.infer_video_depth(frames, 24, fp32=args.fp32)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if backend == "nccl":
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        else:
+            tcpu = tmax.cpu()
+            dist.all_reduce(tcpu, op=dist.ReduceOp.MAX)
+            tmax = tcpu
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    assert out is not None and out.shape == (n, 518, 518) and out.dtype == np.float32 and np.isfinite(out).all() and (out >= 0).all()
+    nw = len(plan_windows(n))
+    prec = "fp32" if args.fp32 else "fp16"
+    peak = 157.3 if args.fp32 else MFMA_PEAK_TFLOPS
+    tflops = CLIP_TFLOP[args.encoder] * nw * args.steps / dt
+    line = {
+        "metric": f"output frames/sec of infer_video_depth on a {n}-frame 518x518 video, {prec}, {'ViT-L' if args.encoder == 'vitl' else 'ViT-S'}",
+        "value": args.steps * n / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32" if args.fp32 else "f16", "data": "synthetic",
+        "config": {"workload": f"{args.encoder} {prec} infer_video_depth, {n} uint8 frames of 518x518 (rng seed 0), {nw} sliding windows of 32 frames "
+                               f"(stride 22), seeded random weights (BASELINE.json configs[3]); host uint8 in -> host fp32 out on rank 0, stitch included "
+                               f"(PCIe-inclusive: the API's boundary)",
+                   "windows": nw, "computed_frames_per_s": args.steps * nw * 32 / dt, "ms_per_window": dt / args.steps / nw * 1e3,
+                   "windows_in_flight_per_gpu": 2, "exchange": args.exchange,
+                   "parallelism": f"windows round-robin over {world} rank(s)" + (", one all-gather per round to stitch, result on rank 0" if world > 1 else ""),
+                   "world": (dist.get_world_size() if dist is not None else 1), "backend": (dist.get_backend() if dist is not None else None)},
+        "model_tflops": tflops, "model_mfma_frac": tflops / (peak * world),
+        "roofline": None, "cpu_baseline": None,
+        "note": "video mode: the per-kernel roofline and the CPU baseline are those of the clip bench (python bench.py), whose kernels these are; "
+                "with two windows in flight per GPU a launch's duration includes co-running kernels and is not reported",
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,13 +199,18 @@ def main():
     ap.add_argument("--cpu-sample", action="store_true", help="time the CPU oracle on 4 of the 32 frames instead of the whole clip (ViT-L: ~10 s instead of ~70 s)")
     ap.add_argument("--fp32", action="store_true", help="bench the fp32-operand path (the reference's --fp32) instead of the headline fp16 path")
     ap.add_argument("--no-inflight2", action="store_true", help="skip the extra (untimed-for-`value`) pass with two clips in flight on two HIP streams")
+    ap.add_argument("--video", type=int, default=0, metavar="N_FRAMES",
+                    help="configs[3]: time infer_video_depth over N synthetic 518x518 frames (output frames/s) instead of the clip forward")
+    ap.add_argument("--exchange", default="windows", choices=["windows", "keys"], help="--video, N > 1: what the ranks exchange per round")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))                 # the parent touches no GPU; the ranks are its grandchildren
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE={world}): pass the same N to both")
     # VDA_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (ranks share devices, the exchange is
     # staged through the host): it exercises the rank / barrier / reduction logic only - never a measurement.
     backend = os.environ.get("VDA_BENCH_BACKEND", "nccl")
@@ -146,6 +236,11 @@ def main():
     model = VideoDepthAnything(encoder=args.encoder, features=cfg.features, out_channels=list(cfg.out_channels))
     model.load_state_dict(synthetic_state_dict(cfg, seed=0), strict=True)
     model = model.to(dev).eval()
+    if args.video > 0:
+        video_bench(args, model, dist, backend, world, rank, dev)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     T, H, W = 32, 518, 518
     x = torch.randn(1, T, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)   # resident in HBM
 

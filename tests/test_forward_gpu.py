@@ -860,6 +860,37 @@ def test_bench_two_ranks_rehearsal(tmp_path):
     assert d["scaling"] == "weak" and d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
 
 
+def test_bench_self_launch_and_video_mode(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the form the driver uses): the parent starts torch.distributed.run as a
+    child process, relays the one JSON line and returns its exit code (VERDICT r3 missing #1). Run for the clip bench and for
+    --video (BASELINE.json configs[3]: infer_video_depth, windows sharded over the ranks, result on rank 0, output frames/s) with
+    2 ranks sharing this GPU over gloo - a rehearsal of the flow, never a measurement."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VDA_BENCH_BACKEND"] = "gloo"
+    for extra, want in ((["--no-inflight2"], "frames/sec at 1x32x518x518 fp16, ViT-S"),
+                        (["--video", "76"], "output frames/sec of infer_video_depth on a 76-frame 518x518 video, fp16, ViT-S"),
+                        (["--video", "76", "--exchange", "keys"], "output frames/sec of infer_video_depth on a 76-frame 518x518 video, fp16, ViT-S")):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--encoder", "vits",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        assert "[bench] --gpus 2 without a launcher" in r.stderr
+        lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        assert len(lines) == 1, "exactly one JSON line, from rank 0"
+        d = json.loads(lines[0])
+        assert d["metric"] == want and d["n_gpus"] == 2 and d["config"]["world"] == 2 and d["config"]["backend"] == "gloo" and d["value"] > 0
+        if "--video" in extra:
+            assert d["scaling"] == "strong" and d["config"]["exchange"] == (extra[-1] if "--exchange" in extra else "windows"), d
+            assert d["config"]["windows"] == 4, d["config"]
+    # one rank, the same entry: config 4's metric on one GPU
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--video", "54", "--steps", "1", "--warmup", "1", "--encoder", "vits"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["windows"] == 3 and d["value"] > 0
+
+
 def test_bench_rccl_calls_at_world_size_one():
     """The RCCL calls of bench.py's multi-rank flow (process-group init bound to the device, all_gather_into_tensor per step, barrier,
     all_reduce of the time) on the real backend - at world size 1, all a one-GPU box allows (VDA_BENCH_FORCE_DIST=1): the API usage
