@@ -122,6 +122,96 @@ def capture_stages(model):
     return store, hs
 
 
+def autocast_fp16(fn):
+    """The reference's fp32=False path (video_depth.py:203-205) as far as a CPU can run it: its own modules under
+    torch.autocast(fp16). This is the ANCHOR of the fp16 tolerance (tests/test_forward_gpu.py): how far the reference's own
+    half-precision path is from its fp32 path on the same input and weights. (On the CPU the fp32 island of dpt_temporal.py:97-100
+    - `autocast(device_type="cuda", enabled=False)` - is not entered, so output_conv2 runs in fp16 here too.)"""
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.float16):
+        return fn()
+
+
+def video_autocast_fp16(model, frames, input_size):
+    """infer_video_depth(fp32=False): the reference opens torch.autocast(device_type=device) itself (video_depth.py:204); on the
+    CPU that defaults to bfloat16, so the CPU autocast dtype is set to float16 around the call."""
+    old = torch.get_autocast_dtype("cpu")
+    torch.set_autocast_dtype("cpu", torch.float16)
+    try:
+        d, _ = model.infer_video_depth(frames, 24, input_size=input_size, device="cpu", fp32=False)
+    finally:
+        torch.set_autocast_dtype("cpu", old)
+    return d.astype(np.float32)
+
+
+class _NetworkSize(Exception):
+    def __init__(self, size):
+        self.size = size
+
+
+def index_logic(model):
+    """Integer / index host logic of infer_video_depth, taken from the reference's OWN code paths (bit-exact tier):
+      sizes   [n, 5] = (H0, W0, input_size, H, W): the network size its aspect guard (video_depth.py:167-171) and
+              Resize.get_size (util/transform.py:51-107) arrive at - read off the cv2.resize call the transform makes;
+      win_<n> [windows, 32]: the SOURCE frame every slot of every window holds (video_depth.py:187-201: padding with the last
+              frame, stride 22, key-frame refill from the previous window's input), obtained by running the reference's loop on
+              a video whose frame i has the value i written into its pixels (base-256 digits over the three channels) and a
+              stand-in forward that only records what it is handed.
+    The model's arithmetic plays no part: `forward` is replaced by the recorder, depth is zeros."""
+    import cv2
+    from video_depth_anything import video_depth as vd
+    out = {"KEYFRAMES": np.array(vd.KEYFRAMES, dtype=np.int32), "INFER_LEN": np.int32(vd.INFER_LEN), "OVERLAP": np.int32(vd.OVERLAP),
+           "INTERP_LEN": np.int32(vd.INTERP_LEN)}
+    real_resize, real_forward = cv2.resize, model.__dict__.get("forward")
+
+    def raise_size(img, size, interpolation=None):
+        raise _NetworkSize(size)
+
+    cv2.resize = raise_size
+    cases = []
+    try:
+        hs = (14, 100, 240, 360, 480, 518, 600, 720, 1080, 1440, 2160)
+        ws = (14, 100, 320, 426, 518, 640, 854, 1000, 1280, 1920, 1930, 2000, 2560, 3840)
+        grid = [(h, w, s) for s in (518, 392, 280, 1022) for h in hs for w in ws]
+        # either side of the 1.78 guard, both orientations; sides just under / over the input size; odd multiples of 14
+        grid += [(1000, w, 518) for w in (1776, 1777, 1778, 1779, 1780, 1781, 1782, 1790)] + [(h, 1000, 518) for h in (1779, 1780, 1781, 1790)]
+        grid += [(517, 517, 518), (519, 519, 518), (511, 525, 518), (525, 511, 518), (7, 7, 518), (21, 700, 518), (700, 21, 518), (533, 947, 518)]
+        for (h0, w0, size) in grid:
+            try:
+                model.infer_video_depth(np.zeros((1, h0, w0, 3), dtype=np.uint8), 24, input_size=size, device="cpu", fp32=True)
+                raise AssertionError("the transform did not call cv2.resize")
+            except _NetworkSize as e:
+                cases.append((h0, w0, size, e.size[1], e.size[0]))
+    finally:
+        cv2.resize = real_resize
+    out["sizes"] = np.array(cases, dtype=np.int32)
+
+    mean, std = np.array([0.485, 0.456, 0.406]), np.array([0.229, 0.224, 0.225])
+    seen = []
+
+    def recorder(x):                                     # x [1, 32, 3, 14, 14], normalised
+        px = x[0, :, :, 0, 0].double().numpy() * std + mean
+        digits = np.rint(px * 255.0).astype(np.int64)
+        seen.append(digits[:, 0] + 256 * digits[:, 1] + 65536 * digits[:, 2])
+        return torch.zeros(1, x.shape[1], x.shape[3], x.shape[4])
+
+    model.forward = recorder
+    try:
+        for n in (1, 5, 22, 23, 32, 33, 54, 55, 100, 1024):
+            idx = np.arange(n)
+            frames = np.stack([idx & 255, (idx >> 8) & 255, (idx >> 16) & 255], axis=-1).astype(np.uint8)[:, None, None, :]
+            frames = np.ascontiguousarray(np.broadcast_to(frames, (n, 14, 14, 3)))
+            seen.clear()
+            d, _ = model.infer_video_depth(frames, 24, input_size=14, device="cpu", fp32=True)
+            assert d.shape == (n, 14, 14)
+            out[f"win_{n}"] = np.stack(seen).astype(np.int32)
+    finally:
+        if real_forward is None:
+            del model.forward
+        else:
+            model.forward = real_forward
+    return out
+
+
 def compare_dirs(fresh, committed):
     """Every array of every freshly generated fixture must equal the committed one exactly."""
     bad = []
@@ -164,7 +254,7 @@ def main():
         frames = rng.integers(0, 256, (50, 42, 56, 3), dtype=np.uint8)
         depths, _ = model.infer_video_depth(frames, 24, input_size=42, device="cpu", fp32=True)
         np.savez_compressed(os.path.join(OUT, "tiny_metric_video.npz"), frames=frames, depths=depths.astype(np.float32),
-                            sd_seed=6, sd_checksum=sd_checksum(sd), input_size=42)
+                            depths_autocast_fp16=video_autocast_fp16(model, frames, 42), sd_seed=6, sd_checksum=sd_checksum(sd), input_size=42)
         print("tiny_metric_video", depths.shape, float(depths.mean()))
         if args.check:
             compare_dirs(OUT, committed)
@@ -190,6 +280,20 @@ def main():
             v = v.permute(0, 2, 1, 3, 4).flatten(0, 1)
             k = k[:-6]
         out[k] = v.numpy()
+    # the fp16 anchor of every array above (same hooks, the reference's modules under fp16 autocast)
+    store16, hooks = capture_stages(model)
+    taps16, depth16 = autocast_fp16(lambda: (model.pretrained.get_intermediate_layers(x.flatten(0, 1), list(cfg.taps), return_class_token=True),
+                                             model.forward(x)))
+    for h in hooks:
+        h.remove()
+    out["depth_autocast_fp16"] = depth16.float().numpy()
+    for i, (t, c) in enumerate(taps16):
+        out[f"tap{i}_autocast_fp16"] = t.float().numpy()
+    for k, v in store16.items():
+        if k.endswith("_bcthw"):
+            v = v.permute(0, 2, 1, 3, 4).flatten(0, 1)
+            k = k[:-6]
+        out[k + "_autocast_fp16"] = v.float().numpy()
     np.savez_compressed(os.path.join(OUT, "tiny_forward.npz"), **out)
     print("tiny_forward", depth.shape, float(depth.mean()), {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
 
@@ -200,7 +304,10 @@ def main():
     frames = rng.integers(0, 256, (50, 42, 56, 3), dtype=np.uint8)
     depths, fps = model.infer_video_depth(frames, 24, input_size=42, device="cpu", fp32=True)
     np.savez_compressed(os.path.join(OUT, "tiny_video.npz"), frames=frames, depths=depths.astype(np.float32),
-                        sd_seed=2, sd_checksum=sd_checksum(sd), input_size=42)
+                        depths_autocast_fp16=video_autocast_fp16(model, frames, 42), sd_seed=2, sd_checksum=sd_checksum(sd), input_size=42)
+    # ---- 2b. integer / index host logic from the reference's own loop (no arithmetic of the model involved)
+    np.savez_compressed(os.path.join(OUT, "index_logic.npz"), **index_logic(model))
+    print("index_logic", "written")
     print("tiny_video", depths.shape, depths.dtype, float(depths.mean()), fps)
 
     # ---- 3. real ViT-S, small non-square clip ------------------------------------
@@ -212,7 +319,7 @@ def main():
     with torch.no_grad():
         depth = model.forward(x)
     np.savez_compressed(os.path.join(OUT, "vits_forward.npz"), x=x.numpy(), depth=depth.numpy(),
-                        sd_seed=0, sd_checksum=sd_checksum(sd))
+                        depth_autocast_fp16=autocast_fp16(lambda: model.forward(x)).float().numpy(), sd_seed=0, sd_checksum=sd_checksum(sd))
     print("vits_forward", depth.shape, float(depth.mean()))
 
     # ---- 4. real ViT-S, one 518x518 frame (stored pos_embed path, 1370 tokens) ----
@@ -221,7 +328,9 @@ def main():
     with torch.no_grad():
         depth = model.forward(x)
     d = depth.numpy()
-    np.savez_compressed(os.path.join(OUT, "vits_518.npz"), x_seed=103, depth_sub=d[..., ::7, ::7],
+    d16 = autocast_fp16(lambda: model.forward(x)).float().numpy()
+    np.savez_compressed(os.path.join(OUT, "vits_518.npz"), x_seed=103, depth_sub=d[..., ::7, ::7], depth_sub_autocast_fp16=d16[..., ::7, ::7],
+                        row_sums_autocast_fp16=d16.sum(axis=-1).astype(np.float64),
                         depth_mean=float(d.mean()), depth_absmax=float(np.abs(d).max()),
                         row_sums=d.sum(axis=-1).astype(np.float64), sd_seed=0, sd_checksum=sd_checksum(sd))
     print("vits_518", depth.shape, float(depth.mean()))
@@ -236,8 +345,14 @@ def main():
         depth = model.forward(x)
     for h in hooks:
         h.remove()
+    store16, hooks = capture_stages(model)
+    depth16 = autocast_fp16(lambda: model.forward(x))
+    for h in hooks:
+        h.remove()
     np.savez_compressed(os.path.join(OUT, "tiny_clstoken_forward.npz"), x=x.numpy(), depth=depth.numpy(), layer_1=store["layer_1"].numpy(),
-                        layer_2=store["layer_2"].numpy(), sd_seed=4, sd_checksum=sd_checksum(sd))
+                        layer_2=store["layer_2"].numpy(), depth_autocast_fp16=depth16.float().numpy(),
+                        layer_1_autocast_fp16=store16["layer_1"].float().numpy(), layer_2_autocast_fp16=store16["layer_2"].float().numpy(),
+                        sd_seed=4, sd_checksum=sd_checksum(sd))
     print("tiny_clstoken_forward", depth.shape, float(depth.mean()))
 
     # ---- 4c / 4d. the two remaining constructor switches of video_depth.py:38-50 (no released configuration sets them): use_bn=True
@@ -253,8 +368,16 @@ def main():
             depth = model.forward(x)
         for h in hooks:
             h.remove()
+        store16, hooks = capture_stages(model)
+        depth16 = autocast_fp16(lambda: model.forward(x))
+        for h in hooks:
+            h.remove()
+        frames_major = lambda v: v.permute(0, 2, 1, 3, 4).flatten(0, 1)          # [B,C,T,h,w] -> [(B T),C,h,w]
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), x=x.numpy(), depth=depth.numpy(), path_2=store["path_2"].numpy(),
-                            path_1=store["path_1"].numpy(), layer_3=store["layer_3_bcthw"].permute(0, 2, 1, 3, 4).flatten(0, 1).numpy(), sd_seed=sd_seed,
+                            path_1=store["path_1"].numpy(), layer_3=frames_major(store["layer_3_bcthw"]).numpy(),
+                            depth_autocast_fp16=depth16.float().numpy(), path_2_autocast_fp16=store16["path_2"].float().numpy(),
+                            path_1_autocast_fp16=store16["path_1"].float().numpy(),
+                            layer_3_autocast_fp16=frames_major(store16["layer_3_bcthw"]).float().numpy(), sd_seed=sd_seed,
                             sd_checksum=sd_checksum(sd))
         print(tag, depth.shape, float(depth.mean()))
 
