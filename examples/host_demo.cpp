@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; ++rep)                      // twice: the second forward allocates nothing
         if (vda_forward(m, dx, dd, B, T, H, W, precision, s)) die("vda_forward", vda_last_error());
     HIP_OK(hipStreamSynchronize(s));
+    if (vda_forward_status(m)) die("vda_forward_status", vda_last_error());      // deferred status of the forwards above (fp16 stream overflow)
     HIP_OK(hipMemcpy(depth.data(), dd, depth.size() * sizeof(float), hipMemcpyDeviceToHost));
 
     f = fopen(argv[3], "wb");

@@ -156,13 +156,15 @@ int vda_layernorm_f32_f32(const float* in, float* out, const float* w, const flo
  * vda_split_center_stats_f32: the same with the row's mean taken out first: hi + lo = x - mean(x), stat[r] = (0, rstd) - the entry
  *   the model uses (the stream then stays relative to each token's mean: VDA_EPI_SCALE_RES_SPLIT's pos).
  * vda_ln_stats_finalize: partial[np, r, 2] (sum, centred sum of squares per 64 columns, as VDA_EPI_SCALE_RES_SPLIT writes them)
- *   -> stat[r] = (mean, rstd), combined in column order (Chan et al.), D = 64*np.
+ *   -> stat[r] = (mean, rstd), combined in column order (Chan et al.), D = 64*np. overflow (device int32, may be NULL) is set to 1
+ *   when a row's statistics are not finite: the fp16 planes hold a token only up to 65 504 from its own mean (the reference's
+ *   stream is fp32, block.py:105-106, and has no such limit); a saturated plane shows as an infinite / NaN sum here.
  * vda_layernorm_split_f16: LayerNorm of x = hi + lo (fp32 statistics), fp16 out, group/skip as vda_layernorm_f32_f16 (the taps).
  * vda_fold_ln_weight: pack-time fold of LayerNorm's affine into the Linear that follows it: Wf[n,k] = fp16(W[n,k]*ln_w[k]),
  *   c1[n] = sum_k Wf[n,k] (of the ROUNDED values, fp32), c2[n] = b[n] + sum_k W[n,k]*ln_b[k] (fp32; b may be NULL). */
 int vda_split_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream);
 int vda_split_center_stats_f32(const float* x, void* hi, void* lo, float* stat, float eps, int rows, int D, vda_stream_t stream);
-int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, vda_stream_t stream);
+int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, int32_t* overflow, vda_stream_t stream);
 int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const float* w, const float* b, float eps,
                             int rows, int D, int group, int skip, vda_stream_t stream);
 int vda_fold_ln_weight(const float* W, const float* bias, const float* ln_w, const float* ln_b, void* Wf, float* c1, float* c2,
@@ -342,6 +344,12 @@ int vda_set_workspace(vda_model* h, void* ptr, int64_t bytes);
 int vda_prepare(vda_model* h, int B, int T, int H, int W, int precision);
 /* in: fp32 device [B,T,3,H,W] (normalised frames; H, W multiples of 14; T <= num_frames) -> out: fp32 device [B,T,H,W]. */
 int vda_forward(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream);
+/* Deferred status of the forwards enqueued so far (vda_forward itself only enqueues). 0 = every forward whose stream work has
+ * COMPLETED was valid; 4 = one of them left fp16's range in the split residual stream of the default fp16 path ("ln_fold": a token
+ * further than 65 504 from its own mean; the reference's stream is fp32, block.py:105-106): its depth was overwritten with NaN and
+ * vda_last_error() names the way out (vda_set_option "ln_fold" 0, or the fp32 path). Call it after synchronising the stream(s);
+ * a report nobody collected fails the NEXT vda_forward instead. Reports are cleared once returned. */
+int vda_forward_status(vda_model* h);
 /* Parity hook: copy `bytes` of a named intermediate of the last forward ("tap0".."tap3", "l1", "l2", "l3t", "l4t", "p4t",
  * "p3t", "p2", "p1"; activation dtype of that forward's precision, channels padded to multiples of 64) to device `dst`. */
 int vda_debug_copy(vda_model* h, const char* name, void* dst, int64_t bytes, vda_stream_t stream);

@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol(libpath):
     lib = ctypes.CDLL(libpath)
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"libvda_hip.so lacks {missing}"
-    assert lib.vda_abi_version() == 7
+    assert lib.vda_abi_version() == 8
 
 
 def test_binding_table_matches_header(libpath):

@@ -52,7 +52,7 @@ SIGNATURES = {
     "vda_layernorm_f32_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "vda_split_stats_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
     "vda_split_center_stats_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _vp]),
-    "vda_ln_stats_finalize": (_i, [_vp, _vp, _f, _i, _i, _vp]),
+    "vda_ln_stats_finalize": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp]),
     "vda_layernorm_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_fold_ln_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
@@ -94,6 +94,7 @@ SIGNATURES = {
     "vda_set_workspace": (_i, [_vp, _vp, C.c_int64]),
     "vda_prepare": (_i, [_vp, _i, _i, _i, _i, _i]),
     "vda_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "vda_forward_status": (_i, [_vp]),
     "vda_debug_copy": (_i, [_vp, C.c_char_p, _vp, C.c_int64, _vp]),
     "vda_set_option": (_i, [_vp, C.c_char_p, _i]),
     "vda_debug_occupy": (_i, [_i, _i, _ll, _vp]),

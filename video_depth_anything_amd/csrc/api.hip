@@ -12,7 +12,7 @@ extern "C" void vda_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vda_last_error(void) { return g_err; }
-extern "C" int vda_abi_version(void) { return 7; }
+extern "C" int vda_abi_version(void) { return 8; }
 
 // Test utility (tools/contention.py): occupy `wgs` compute units' worth of workgroups (256 threads, `lds_bytes` of LDS each) for
 // about `cycles` shader clocks - a stand-in for a communication kernel (RCCL's channel workgroups) running beside the forward.

@@ -100,6 +100,13 @@ inline unsigned grid_for(size_t items) {
 #define VDA_LN_FOLD_DEFAULT 1
 #endif
 
+// A forward whose split residual stream left fp16's range has no valid result: its depth is overwritten with NaN so that the
+// failure is visible in the data as well as in the status (a clamped ReLU would otherwise turn NaN activations into zeros).
+__global__ void __launch_bounds__(256) poison_on_overflow_kernel(const int* __restrict__ flag, float* __restrict__ depth, long long n) {
+    if (*flag == 0) return;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) depth[i] = __builtin_nanf("");
+}
+
 struct Raw {
     float* d = nullptr;
     std::vector<int64_t> dims;
@@ -155,6 +162,11 @@ struct vda_model {
                                               // processes that share the GPU with communication kernels (multi-rank runs turn it on)
     int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
     int oc1_fused = 1;                        // vda_set_option("oc1_fused"): refinenet1's 2x upsample folded into output_conv1 (fp16 path)
+    // Split-stream overflow reports (ln_fold): each forward's device flag is copied, at its end and on its stream, into the next
+    // word of this pinned ring; vda_forward_status / the next vda_forward read the words whose forwards have completed.
+    static constexpr int OVF_RING = 16;
+    volatile int32_t* ovf_host = nullptr;     // hipHostMalloc'ed [OVF_RING]
+    unsigned long long forwards = 0;          // forwards enqueued so far (ring position)
 };
 
 namespace {
@@ -731,6 +743,10 @@ struct Run {
         void* tlo = fold ? buf("tok_lo", (size_t)rows * D, 2) : nullptr;
         float* lnpart = fold ? f32("ln_part", (size_t)rows * (D / 64) * 2) : nullptr;
         float* lnstat = fold ? f32("ln_stat", (size_t)rows * 2) : nullptr;
+        // overflow flag of this forward (see vda_model::ovf_host): raised by vda_ln_stats_finalize when a row's statistics are not
+        // finite, i.e. when a token moved further than 65 504 from its own mean and saturated the fp16 hi plane
+        int32_t* ovf = fold ? (int32_t*)buf("overflow", 1, 4) : nullptr;
+        if (fold && !dry) VDA_HIP(hipMemsetAsync(ovf, 0, 4, s));
         // The planes hold every token RELATIVE TO ITS OWN MEAN: taken out here, and again by every residual epilogue (a.pos below:
         // the mean the preceding LayerNorm statistics found), so the operand plane's fp16 rounding is relative to the token's
         // spread whatever offset the stream carries (tests/_outliers.py "offset": mean / sigma ~ 20 cost 15x the standalone
@@ -749,7 +765,9 @@ struct Run {
             a.pos = lnstat;                      // re-centre by the mean the LayerNorm before this branch saw
             a.M = rows, a.N = D, a.K = K, a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_SCALE_RES_SPLIT;
             VDA_TRY(gemm(a));
-            if (stats_next && !dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, s));
+            // (after the last block nothing reads the statistics: that finalize runs for its overflow check alone, 5 us per clip)
+            (void)stats_next;
+            if (!dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, ovf, s));
             return 0;
         };
         auto tap_ln = [&](void* out, int group, int skip) -> int {
@@ -897,6 +915,12 @@ struct Run {
             if (!dry) VDA_TRY(vda_head_out_f32_f32((const float*)c2, V("oc3.w"), h->oc3_bias, depth, (long long)BT * H * Wd, 32, s));
         }
         // video_depth.py:162-163: bilinear to (H,W) is the identity here (H == 14*ph) and the final ReLU is idempotent.
+        if (fold && !dry) {
+            hipLaunchKernelGGL(poison_on_overflow_kernel, dim3(256), dim3(256), 0, s, (const int*)ovf, depth, (long long)BT * H * Wd);
+            VDA_LAUNCH_CHECK();
+            VDA_HIP(hipMemcpyAsync((void*)(h->ovf_host + h->forwards % vda_model::OVF_RING), ovf, 4, hipMemcpyDeviceToHost, s));
+            ++h->forwards;
+        }
         return 0;
     }
 };
@@ -962,12 +986,22 @@ extern "C" int vda_create(const vda_config* cfg, vda_model** out) {
         vda_set_error("vda_create: device allocation failed");
         return 2;
     }
+    void* ring = nullptr;
+    if (hipHostMalloc(&ring, sizeof(int32_t) * vda_model::OVF_RING, hipHostMallocDefault) != hipSuccess) {
+        for (void* p : h->owned) (void)hipFree(p);
+        delete h;
+        vda_set_error("vda_create: pinned host allocation failed");
+        return 2;
+    }
+    memset(ring, 0, sizeof(int32_t) * vda_model::OVF_RING);
+    h->ovf_host = (volatile int32_t*)ring;
     *out = h;
     return 0;
 }
 
 extern "C" int vda_destroy(vda_model* h) {
     if (h == nullptr) return 0;
+    if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
     for (void* p : h->owned) (void)hipFree(p);
     delete h;
     return 0;
@@ -1077,9 +1111,32 @@ extern "C" int vda_set_workspace(vda_model* h, void* ptr, int64_t bytes) {
     return 0;
 }
 
+// Overflow reports that have ARRIVED (their forward's stream work has completed): collected and cleared. A word still in flight
+// reads 0 and is seen by a later call. Status 4 + a message naming the way out.
+static int collect_overflow(vda_model* h, const char* who) {
+    bool any = false;
+    for (int i = 0; i < vda_model::OVF_RING; ++i) {
+        if (h->ovf_host[i] != 0) {
+            any = true;
+            h->ovf_host[i] = 0;
+        }
+    }
+    if (!any) return 0;
+    vda_set_error("%s: in a forward since the last check the split residual stream left fp16's range (a token further than 65504 from its own "
+                  "mean): that forward's depth was overwritten with NaN. vda_set_option(h, \"ln_fold\", 0) keeps the stream in fp32 (the reference's "
+                  "form, no such limit); fp32=True avoids it as well", who);
+    return 4;
+}
+
+extern "C" int vda_forward_status(vda_model* h) {
+    VDA_REQUIRE(h != nullptr, "vda_forward_status: null handle");
+    return collect_overflow(h, "vda_forward_status");
+}
+
 static int vda_forward_impl(vda_model* h, const float* in, float* out, int B, int T, int H, int W, int precision, vda_stream_t stream) {
     VDA_REQUIRE(h && in && out, "vda_forward: null argument");
     VDA_REQUIRE(h->finalized, "vda_forward: load every weight and call vda_finalize_weights first");
+    VDA_TRY(collect_overflow(h, "vda_forward"));          // an EARLIER forward's report, if nobody asked (never silent)
     VDA_TRY(vda_prepare(h, B, T, H, W, precision));
     Layout* lay = nullptr;
     VDA_TRY(get_layout(h, B, T, H, W, precision, &lay));

@@ -318,7 +318,10 @@ __global__ void __launch_bounds__(256) ln_split_kernel(const float* __restrict__
 
 // partial[np, r, 2] = (sum, centred sum of squares) per 64 columns -> stat[r] = (mean, rstd); pairwise update in column order
 // (Chan, Golub, LeVeque): no E[x^2] - mean^2 cancellation, fixed order.
-__global__ void __launch_bounds__(64) ln_stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, float eps, int rows, int np) {
+// overflow (optional): set to 1 when a row's statistics are not finite - the fp16 planes of the split stream saturate at 65 504 from
+// the token's own mean, and a saturated hi plane shows here as an infinite / NaN sum (every element of it is under these sums).
+__global__ void __launch_bounds__(64) ln_stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, float eps, int rows, int np,
+                                                               int* __restrict__ overflow) {
     const int r = blockIdx.x * 64 + threadIdx.x;          // one wave per workgroup: 685 workgroups for a ViT-L clip, every CU gets some
     if (r >= rows) return;
     const float2* p = reinterpret_cast<const float2*>(partial) + r;
@@ -341,6 +344,7 @@ __global__ void __launch_bounds__(64) ln_stats_finalize_kernel(const float* __re
         }
     }
     *reinterpret_cast<float2*>(stat + 2 * (size_t)r) = float2{mean, rsqrtf(m2 / n + eps)};
+    if (overflow != nullptr && !(__builtin_isfinite(mean) && __builtin_isfinite(m2))) *overflow = 1;      // (same value from every writer)
 }
 
 // Pack-time fold of LayerNorm's affine into the following Linear: one wave per output row.
@@ -456,10 +460,10 @@ extern "C" int vda_layernorm_split_f16(const void* hi, const void* lo, void* out
     return ln_split_launch<1>(nullptr, (const h16*)hi, (const h16*)lo, (h16*)out, nullptr, nullptr, w, b, eps, rows, D, group, skip, stream);
 }
 
-extern "C" int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, vda_stream_t stream) {
+extern "C" int vda_ln_stats_finalize(const float* partial, float* stat, float eps, int rows, int np, int32_t* overflow, vda_stream_t stream) {
     VDA_REQUIRE(partial && stat && rows > 0 && np > 0, "vda_ln_stats_finalize: bad arguments");
     VDA_REQUIRE(((uintptr_t)partial & 7) == 0 && ((uintptr_t)stat & 7) == 0, "vda_ln_stats_finalize: 8-byte alignment required");
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, stat, eps, rows, np);
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((rows + 63) / 64), dim3(64), 0, (hipStream_t)stream, partial, stat, eps, rows, np, (int*)overflow);
     VDA_LAUNCH_CHECK();
     return 0;
 }

@@ -115,6 +115,15 @@ class ModelHandle:
             self._last = (B * T, H // 14, W // 14, fp32)
         return out
 
+    def check(self, synchronize=True):
+        """Deferred status of the forwards enqueued so far (vda_forward_status): raises VdaError if one of them left fp16's range in
+        the split residual stream (its depth is NaN). forward() only enqueues work, so this is where such a failure surfaces;
+        infer_video_depth calls it before it returns, a bare forward() reports at the next forward() at the latest."""
+        with torch.cuda.device(self.device):
+            if synchronize:
+                torch.cuda.synchronize(self.device)
+            _check(lib.vda_forward_status(self._h), "vda_forward_status")
+
     # ------------------------------------------------------------------ parity / measurement hooks
     def stage(self, name):
         """A named intermediate of the last forward as (tensor [rows, Cpad], h, w, Cpad): 'tap0'..'tap3', 'layer_1'..'layer_4',

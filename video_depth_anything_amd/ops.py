@@ -136,10 +136,10 @@ def split_stats(x, hi, lo, stat, eps, rows, D, center=False):
     check(fn(_p(x), _p(hi), _p(lo), _p(stat), eps, rows, D, _stream(x)), "vda_split_stats_f32")
 
 
-def ln_stats_finalize(partial, stat, eps, rows, np_):
+def ln_stats_finalize(partial, stat, eps, rows, np_, overflow=None):
     """partial[np, r, 2] (sum, centred sum of squares per 64 columns) -> stat[r] = (mean, rstd)."""
     _req(partial, F32, "partial"), _req(stat, F32, "stat")
-    check(lib.vda_ln_stats_finalize(_p(partial), _p(stat), eps, rows, np_, _stream(partial)), "vda_ln_stats_finalize")
+    check(lib.vda_ln_stats_finalize(_p(partial), _p(stat), eps, rows, np_, _p(overflow), _stream(partial)), "vda_ln_stats_finalize")
 
 
 def layernorm_split(hi, lo, out, w, b, eps, rows, D, group=0, skip=0):

@@ -276,11 +276,12 @@ class VideoDepthAnything:
             if self.result_ranks is not None and rank not in self.result_ranks:
                 for _ in pieces:
                     pass
-                torch.cuda.synchronize(dev)
+                eng.check()
                 return None, target_fps
             depths = collect_pieces(pieces, n, H0, W0, dev, on_copied=kops.copied)
             for lane in lanes:
                 compute.wait_stream(lane)
+            eng.check()                                   # a window whose residual stream left fp16's range is an error, not a NaN video
             return depths, target_fps
 
         # One process per GPU: rank r computes windows r, r + world, ... with no data-path collective; after each round the
@@ -291,11 +292,12 @@ class VideoDepthAnything:
         if self.result_ranks is not None and rank not in self.result_ranks:
             for _ in windows:                                                    # compute and exchange; no stitch, no D2H
                 pass
-            torch.cuda.synchronize(dev)
+            eng.check()
             return None, target_fps
         depths = stitch_stream(windows, n, H0, W0, dev, metric=self.METRIC)
         for lane in lanes:
             compute.wait_stream(lane)
+        eng.check()
         return depths, target_fps
 
 
