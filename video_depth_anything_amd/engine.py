@@ -1,4 +1,9 @@
-"""Host-side orchestration of one forward pass over the HIP kernels.
+"""Host-side orchestration of one forward pass over the HIP kernels - a TEST INSTRUMENT, not the product path.
+
+What ships is `vda_forward` (csrc/host.hip) behind `handle.ModelHandle`. This file is the same launch sequence written in Python
+over the per-kernel ABI, kept as the bit-exact cross-check of the handle IN ITS `ln_fold = 0` FORM ONLY (standalone LayerNorms,
+fp32 residual stream): it does not mirror the default LayerNorm-folded split stream, and it refuses `use_bn` / `pe='rope'`
+(`VideoDepthAnything.python_engine`). tests/test_forward_gpu.py::test_handle_and_python_orchestration_are_bit_identical is its user.
 
 This is the Python mirror of `VideoDepthAnything.forward`
 (/root/reference/video_depth_anything/video_depth.py:89-93,161-164): DINOv2 encoder taps

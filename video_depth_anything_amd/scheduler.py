@@ -150,7 +150,7 @@ def drive_windows_keys(n_windows: int, world: int, rank: int, ops, result_ranks=
     ops.deliver(s, j)          collective: the pieces of round j's windows to the result ranks; returns [(k, frames)] there, [] elsewhere
     ops.last_tail(k, owner)    the last window's aligned tail (8 frames): the chain holds it on every rank (its key frames are slots 24..31)
     Round j's key gather runs under round j + 1's compute; the chain, the finalisation and the delivery of a round happen one
-    round behind, exactly as drive_windows harvests."""
+    round behind, exactly as drive_windows harvests (and are issued before the next round's gather)."""
     mine = lambda k: k % world == rank                     # noqa: E731 - round-robin shards (shard_windows)
     wanted = result_ranks is None or rank in result_ranks
     pending = None
@@ -176,9 +176,12 @@ def drive_windows_keys(n_windows: int, world: int, rank: int, ops, result_ranks=
         k = j * world + rank
         if k < n_windows:
             ops.compute(k, s)
-        h = ops.gather_keys(s)
+        # Round j-1's delivery is issued BEFORE round j's key gather: on the process group's one RCCL stream a collective queues
+        # behind the ones issued before it, and gather_keys(j) waits for round j's compute - behind it the pieces of round j-1
+        # would reach the result ranks a whole round late. Every rank issues the collectives in this same order.
         if pending is not None:
             yield from harvest(pending)
+        h = ops.gather_keys(s)
         pending = (j, s, h)
     yield from harvest(pending)
     last = n_windows - 1
