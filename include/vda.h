@@ -112,6 +112,15 @@ int vda_gemm_f32(const vda_gemm_args* args, vda_stream_t stream);
  * (an A/B form: not what -1 picks, see gemm.hip); 5 + 16*64 = 8-phase on 192x256 tiles where built. Environment: VDA_CONV_LDS, VDA_GEMM_8P128, VDA_GEMM_BIG_MIN_N,
  * VDA_GEMM_STAGGER, VDA_GEMM_BM192 (defaults 1, 0, 192, 0, 1). */
 int vda_gemm_set_variant(int v);
+/* Diagnostic switches of the 8-phase kernel (0 = none; never set by the model). Bit 0: clock stamps - thread 0 of every workgroup
+ * writes (s_memtime, s_memrealtime) at tile start / K-loop start / K-loop end / tile end of its first 16 tiles into args.pos as
+ * int64 [workgroups][16][4][2] (an epilogue that does not use pos; the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz:
+ * tools/gemm_clock.py). Bit 1: L2-blocked tile order (an XCD keeps four column panels for the whole launch). Bit 2 (with bit 0): the
+ * shader clock at the top of the first 32 K tiles of each workgroup's second tile, int64 [workgroups][32] behind the tile stamps. */
+int vda_gemm_set_debug(int flags);
+/* Cap on the workgroups the persistent GEMM / conv kernels launch (0 = one per CU, the default; a multiple of 8): lets two
+ * independent launch sequences on two streams take half the chip each instead of queueing behind each other's full grids. */
+int vda_set_max_wgs(int n);
 /* Row split of a large dense GEMM on the current device: returns M1 <= M. Rows [0, M1) fill whole rounds of 256 x 256 tiles on the
  * device's CUs; rows [M1, M) run as one more call with tile_rows = 192 (a 192-row round costs ~0.8 of a 256-row one). M1 == M: no
  * split pays (or the epilogue / shape has no 192-row kernel). vda_gemm_f16 applies the same plan by itself when sched == NULL and

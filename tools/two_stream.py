@@ -13,6 +13,9 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 cfg = get_config(enc)
 sd = synthetic_state_dict(cfg, seed=0)
 NS = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+if len(sys.argv) > 4:                                    # cap on the persistent kernels' grids (e.g. 128: each stream takes half the chip)
+    from video_depth_anything_amd import _lib
+    _lib.lib.vda_set_max_wgs(int(sys.argv[4]))
 ms = []
 for _ in range(NS):
     m = VideoDepthAnything(encoder=enc, features=cfg.features, out_channels=list(cfg.out_channels))

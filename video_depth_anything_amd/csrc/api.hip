@@ -14,6 +14,12 @@ extern "C" void vda_set_error(const char* fmt, ...) {
 extern "C" const char* vda_last_error(void) { return g_err; }
 extern "C" int vda_abi_version(void) { return 8; }
 
+int g_vda_max_wgs = 0;
+extern "C" int vda_set_max_wgs(int n) {
+    g_vda_max_wgs = n > 0 ? n : 0;
+    return 0;
+}
+
 // Test utility (tools/contention.py): occupy `wgs` compute units' worth of workgroups (256 threads, `lds_bytes` of LDS each) for
 // about `cycles` shader clocks - a stand-in for a communication kernel (RCCL's channel workgroups) running beside the forward.
 // Every wave leaves after `cycles` clocks at the latest: the loop is bounded by the clock and by an iteration count.

@@ -269,6 +269,13 @@ extern "C" int vda_gemm_set_variant(int v) {
     return 0;
 }
 
+static int g_gemm_debug = 0;      // diagnostic switches of the 8-phase kernel (bit 0 clock stamps into pos, bit 1 L2-blocked tile order)
+
+extern "C" int vda_gemm_set_debug(int flags) {
+    g_gemm_debug = flags & 0xff;
+    return 0;
+}
+
 static int device_cus() {
     static thread_local int ncu = 0;
     if (ncu == 0) {
@@ -277,7 +284,8 @@ static int device_cus() {
         (void)hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev);
         ncu = cu < 8 ? 8 : (cu & ~7);
     }
-    return ncu;
+    const int cap = g_vda_max_wgs;             // vda_set_max_wgs: the planner's rounds are rounds of the CAPPED grid
+    return (cap >= 8 && cap < ncu) ? (cap & ~7) : ncu;
 }
 
 static bool bm192_epilogue(int epilogue) {
@@ -466,6 +474,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
         if (!stagger) a8.relu_in |= 16 << 8;
         if (stagger == 2) a8.relu_in |= 32 << 8;             // A/B: panel-aligned phases
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
+        a8.relu_in |= g_gemm_debug << 16;                      // vda_gemm_set_debug (0 unless a diagnostic tool set it)
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
         // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles
         // (ViT-S proj / fc2: 3 against 2.25; variant 8 forces them). Only the one-barrier 256 x 128 family has the shape.

@@ -42,7 +42,12 @@ __device__ __forceinline__ void vm_wait_keep() {
 // phase). A row's arithmetic is the same in either tile (same K order, same epilogue), so a GEMM may be cut by rows into a part
 // that fills whole rounds of 256-row tiles and a remainder on 192-row tiles whose single round costs ~0.8 of a 256-row round:
 // M = 43 840 leaves 2.69 / 8.06 rounds (proj and fc2 / qkv) that ran as 3 / 9 (vda_gemm_plan_split, gemm.hip).
-template <int BN, int AMODE, int EPI, int SCHED = 1, int BM = 256>
+// DYN = the dynamic tile draw (vda_gemm_args.sched) is compiled in. A TEMPLATE parameter, not a runtime test of p.sched: the draw is
+// a returning atomic, and with it in the code - executed or not - hipcc's waitcnt pass parks `s_waitcnt vmcnt(0)` at the top of every
+// tile (the atomic's destination VGPR is re-initialised there and may still be in flight as far as the pass can tell). That wait
+// drains the previous epilogue's whole store burst and the prefetched K tile 0: ~4 k cycles per tile in EVERY launch, found in round 4
+// (tools/gemm_ramp.py + the ISA). The static-schedule kernel (what a single-stream forward runs) now has no atomic in it at all.
+template <int BN, int AMODE, int EPI, int SCHED = 1, int BM = 256, bool DYN = false>
 __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     static_assert(BM == 256 || (BM == 192 && BN == 256 && AMODE == VDA_A_DENSE), "192-row tiles: dense A, 256 columns");
     constexpr int WN = BN == 256 ? 4 : 2;          // waves along N
@@ -77,7 +82,21 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // the plain mapping stays). A workgroup without a tile in that round has one tile time of slack: see the stagger below.
     const int full_rounds = ntiles / nwg, rem = ntiles - full_rounds * nwg;
     const bool deal_last = rem > 0 && full_rounds > 0 && per_xcd % nbn == 0;
+    // DIAGNOSTIC switches (vda_gemm_set_debug, never set by the model): bit 0 = clock stamps (below), bit 1 = L2-BLOCKED tile order.
+    // Blocked order: an XCD keeps ONE group of four column panels for the whole launch (its W slice, 4 x 256 x K x 2 B = 2 MB at
+    // K = 1024, stays in its 4 MB L2) and walks down the row panels, eight per round, interleaved with the other XCDs of its column
+    // group - instead of 32 consecutive tiles per round (N fastest), which at nbn = 16 re-fetches all 8 MB of W past L2 every
+    // round (fc1: 832 MB fetched per launch against 98 MB algorithmic, profiles/r03). Needs nbn = 4, 8, 16 or 32 and 32 workgroups
+    // per XCD; any other shape keeps the default walk.
+    const int dbg2 = __builtin_amdgcn_readfirstlane((p.relu_in >> 16) & 0xff);
+    const int cgroups = nbn >> 2;
+    const bool blocked = (dbg2 & 2) && (nbn & 3) == 0 && cgroups >= 1 && cgroups <= 8 && (8 % cgroups) == 0 && per_xcd == 32 && !DYN;
     auto tile_of = [&](int round) {
+        if (blocked) {
+            const int x = bid & 7, slot = bid >> 3, xpg = 8 / cgroups;
+            const int rp = (round * xpg + x / cgroups) * 8 + (slot >> 2), cp = (x % cgroups) * 4 + (slot & 3);
+            return rp < nbm ? rp * nbn + cp : ntiles;
+        }
         if (deal_last && round == full_rounds) {
             const int slot = bid >> 3, j = ((slot / nbn) * 8 + (bid & 7)) * nbn + slot % nbn;
             return j < rem ? round * nwg + j : ntiles;
@@ -91,11 +110,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // tiles instead of running its fixed share one shift late: with the static walk a foreign kernel costs ~35 % of its active
     // time (tools/contention.py). The draw for tile i+2 is issued by lane 0 of wave 0 at the top of tile i+1 ... i.e. one tile
     // ahead of its use, and handed to the other waves through LDS at the K loop's last barrier.
-    const bool dyn = p.sched != nullptr;
+    constexpr bool dyn = DYN;                  // (the launcher picks the instantiation by p.sched != NULL)
     const int xq = ntiles >> 3, xr = ntiles & 7;
     const int xb = (bid & 7) * xq + min(bid & 7, xr), xc = xq + ((bid & 7) < xr ? 1 : 0);
-    const bool drawer = dyn && wave == 0;                          // wave-uniform
-    int fetched = 0;
+    const bool drawer = dyn && wave == 0;                          // wave-uniform (constant false without DYN)
     volatile VDA_LDS_AS int* const sched_slot =
         (volatile VDA_LDS_AS int*)(smem + 3 * A_BYTES + BN * ROW_BYTES + NW * 1024);      // W slot 1, past the statistics slices
 
@@ -269,13 +287,6 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         }
     };
 
-    // the draw: index (inside the XCD's range) of the tile after next; the youngest vector-memory operation of wave 0 when issued
-    auto draw = [&]() {
-        // (built with -mllvm -amdgpu-atomic-optimizer-strategy=None, build.py: the optimizer would broadcast the uniform result at
-        // once, behind an s_waitcnt vmcnt(0) that also drains the LDS-DMA just issued; as a plain returning atomic the compiler waits
-        // for it where `fetched` is first read - after the K loop - and keeps every copy of it behind that wait)
-        if (drawer && lane == 0) fetched = __hip_atomic_fetch_add(p.sched + (bid & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
     int tile = dyn ? ((bid >> 3) < xc ? xb + (bid >> 3) : ntiles) : tile_of(0);
     if (tile >= ntiles) return;                        // uniform per workgroup
     // Start stagger (VDA_GEMM_STAGGER=1, OFF by default). All workgroups run the same tile time, so their epilogues hit HBM
@@ -303,8 +314,35 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // tile start / K-loop start / K-loop end / tile end into the (otherwise unused) pos operand.
     const bool stamp = EPI != VDA_EPI_PATCH_F32 && ((p.relu_in >> 9) & 1) && p.pos != nullptr && tid == 0;
     long long* stamps = (long long*)p.pos;
+    // Clock stamps (vda_gemm_set_debug bit 0; MI355X_MICROARCH.md "DVFS give-back" item 6): thread 0 of every workgroup writes
+    // (s_memtime = shader clock, s_memrealtime = 100 MHz) at tile start / K-loop start / K-loop end / tile end of its first 16 tiles
+    // into pos, [workgroup][tile][4][2] int64. Diagnostic only: the buffer is read by nothing, no output depends on it, and a build
+    // without the flag executes none of it (the flag is a wave-uniform scalar test).
+    const bool stamp2 = EPI != VDA_EPI_PATCH_F32 && EPI != VDA_EPI_SCALE_RES_SPLIT && (dbg2 & 1) && p.pos != nullptr && tid == 0;
+    auto clk = [&](int round, int which) {
+        if (stamp2 && round < 16) {
+            long long* q = (long long*)p.pos + ((size_t)(bid * 16 + round) * 4 + which) * 2;
+            q[0] = (long long)__builtin_amdgcn_s_memtime();
+            q[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
+    };
     for (int round = 0; tile < ntiles; ++round) {
+        // The draw's result lives INSIDE one iteration (issued at the tile's top, consumed behind its K loop). Declared outside the
+        // loop it was a loop-carried VGPR defined by a returning atomic, and hipcc then parks an `s_waitcnt vmcnt(0)` on the loop's
+        // back edge - in every build, dynamic schedule or not: each tile ended by draining its whole store burst AND the next
+        // tile's prefetched K tile 0 (~4 k cycles per tile; found with tools/gemm_ramp.py + the ISA, round 4).
+        int fetched = 0;
+        // the draw: index (inside the XCD's range) of the tile after next; the youngest vector-memory operation of wave 0 when issued
+        auto draw = [&]() {
+            // (built with -mllvm -amdgpu-atomic-optimizer-strategy=None, build.py: the optimizer would broadcast the uniform result at
+            // once, behind an s_waitcnt vmcnt(0) that also drains the LDS-DMA just issued; as a plain returning atomic the compiler waits
+            // for it where `fetched` is first read - after the K loop - and keeps every copy of it behind that wait)
+            if constexpr (DYN) {
+                if (drawer && lane == 0) fetched = __hip_atomic_fetch_add(p.sched + (bid & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        };
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 0] = __builtin_readcyclecounter();
+        clk(round, 0);
         const int bm = tile / nbn, bn = tile - bm * nbn;
         const int m0 = bm * BM, n0 = bn * BN;
 
@@ -343,6 +381,10 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 stage_w(1, smem + W_BASE + W_BYTES, 0, WH);         // the second half of W's rows of K tile 1 follows in phase 1
                 draw();
                 if (drawer) vm_wait_keep<AJ + WH + 1>();            // (the draw stays in flight with K tile 1)
+                // (This wait also drains the previous epilogue's stores - vmcnt retires in order and counts them. Round 4 tried a
+                // count that leaves the stores issued after the K tile 0 prefetch in flight, vmcnt(AJ + WH + 12): the prologue
+                // fell from 3.9 k to 0.8 k cycles and the first K tiles slowed by as much - the store burst has to drain through
+                // HBM either way; fc1 414.8 us against 404.0 with the full drain, in one process. Not kept.)
                 else vm_wait_keep<AJ + WH>();
             } else {
                 stage_w(1, smem + W_BASE + W_BYTES);
@@ -356,11 +398,15 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         }
         bar();                                  // ... and everyone's
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 1] = __builtin_readcyclecounter();
+        clk(round, 1);
         if (grp == 1) bar();                    // waves 4..7 run one barrier behind from here to the end of the K loop
 
         int sa = 0;                             // A slot of K tile kt (kt % 3)
         tap_of(2);                              // conv: (tap, channel slice) of the next K tile to stage, advanced per K tile
         for (int kt = 0; kt < nt; ++kt) {
+            // (diagnostic, vda_gemm_set_debug bit 2: the shader clock at the top of each of the first 32 K tiles of the workgroup's
+            // SECOND tile, behind the tile stamps: where the K loop's ramp-up goes)
+            if (stamp2 && (dbg2 & 4) && round == 1 && kt < 32) ((long long*)p.pos)[(size_t)nwg * 16 * 4 * 2 + bid * 32 + kt] = (long long)__builtin_amdgcn_s_memtime();
             const char* ab = smem + sa * A_BYTES;
             const char* wb = smem + W_BASE + (kt & 1) * W_BYTES;
             const int sa2 = sa == 0 ? 2 : sa - 1;                   // (kt + 2) % 3
@@ -454,18 +500,21 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             }
             sa = sa == 2 ? 0 : sa + 1;
         }
-        if (drawer) {                           // hand the drawn index to the other waves (W slot 1 is idle: every read of the K loop is done)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the draw has landed (nothing else is in flight here)
-            if (lane == 0) *sched_slot = fetched + per_xcd;
-            lgkm0();
+        if constexpr (DYN) {
+            if (drawer) {                       // hand the drawn index to the other waves (W slot 1 is idle: every read of the K loop is done)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the draw has landed (nothing else is in flight here)
+                if (lane == 0) *sched_slot = fetched + per_xcd;
+                lgkm0();
+            }
         }
         if (grp == 0) bar();                    // re-align the two groups: every wave is past its last MFMA section's reads
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 2] = __builtin_readcyclecounter();
+        clk(round, 2);
         // Nobody reads the pipeline buffers any more. The NEXT tile's first K tile is issued after the first 32-row block of
         // the epilogue (below): early enough that the rest of the epilogue covers its HBM/L2 latency, late enough that the
         // epilogue's own first loads (column constants, residual rows) do not queue behind it on the in-order vmcnt.
         int next = tile_of(round + 1);
-        if (dyn) {
+        if constexpr (DYN) {
             const int idx = __builtin_amdgcn_readfirstlane(*sched_slot);
             next = idx < xc ? xb + idx : ntiles;
         }
@@ -501,8 +550,28 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
             const bool geglu_idle = (EPI == VDA_EPI_GEGLU_F16) && (c0 & 7) >= 4;   // gate lanes only feed their value lanes
             vda_gemm::ColConst<NC> cc;
             vda_gemm::load_col_const<EPI, NC, false>(p, en, cc);
+            // The column constants are loaded under lane / pointer conditions, so hipcc's waitcnt pass sees them as "possibly still in
+            // flight" on some path into EVERY later join (each 32-row block is an interior | guarded diamond) and parks an
+            // `s_waitcnt vmcnt(0)` at the first use in every block and at the top of the next tile: each one drained the whole store
+            // burst issued so far, and the first also the prefetched K tile 0 (33 vmcnt waits in the fc1 kernel's ISA, 7 with this).
+            // Consuming them HERE, on the one path every lane takes, makes the pass wait once - where only these loads are in flight.
+#pragma unroll
+            for (int i2 = 0; i2 < NC; ++i2) asm volatile("" ::"v"(cc.bias[i2]), "v"(cc.gamma[i2]), "v"(cc.gbias[i2]));
             constexpr int RG = RT::f32_out ? 4 : 2;                          // rows per row group
             vda_gemm::RowAux carry[RG];                                      // the next block's first group, loaded a group early
+            // LayerNorm-folded epilogues: every (mean, rstd) pair this lane will need (one per row step: MI/2 blocks x RR steps) is
+            // read from the wave's statistics slice NOW, before the next tile's K tile 0 is put in flight. A read of that slice with an
+            // LDS-DMA pending gets an `s_waitcnt vmcnt(0)` from hipcc (it cannot tell the slice from the DMA's destination; the
+            // staging reads, at constant offsets from another base, do not): one per 32-row block, each draining every store issued so
+            // far and, in block 1, the K tile 0 prefetch itself (ISA, round 4). 32 VGPRs, inside what the dying accumulators free.
+            float2 lnst[LN_EPI ? MI / 2 : 1][LN_EPI ? RR : 1];
+            if constexpr (LN_EPI) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (this lane's slice writes above: same wave, program order)
+#pragma unroll
+                for (int b = 0; b < MI / 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) lnst[b][r] = *reinterpret_cast<const float2*>(sst + (b * 32 + r * (32 / RR) + lrow_e) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < MI / 2; ++i) {
 #pragma unroll
@@ -527,9 +596,8 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                         if constexpr (LN_EPI) {
 #pragma unroll
                             for (int q = 0; q < RG; ++q) {
-                                const float2 st = *reinterpret_cast<const float2*>(sst + (blk * 32 + (r0 + q) * (32 / RR) + lrow_e) * 8);
-                                ax[q].s0 = st.x;
-                                ax[q].s1 = st.y;
+                                ax[q].s0 = lnst[blk][r0 + q].x;
+                                ax[q].s1 = lnst[blk][r0 + q].y;
                             }
                         } else if (!geglu_idle) {
 #pragma unroll
@@ -610,6 +678,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         lgkm0();
         bar();
         if (stamp) stamps[(bid * 16 + (round & 15)) * 4 + 3] = __builtin_readcyclecounter();
+        clk(round, 3);
         tile = next;
     }
 }
@@ -618,13 +687,23 @@ template <int BN, int AMODE, int EPI, int SCHED = 1, int BM = 256>
 int launch256(const vda_gemm_args& a, hipStream_t s) {
     constexpr int smem = 3 * BM_MAX * ROW_BYTES + 2 * BN * ROW_BYTES;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static VdaKernelDeviceState dev_state;
-    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED, BM>), smem, dev_state);
-    if (num_cu < 0) return 2;
     const int nbm = (a.M + BM - 1) / BM, nbn = (a.N + BN - 1) / BN;
     const int ntiles = nbm * nbn;
+    if constexpr (SCHED == 1) {
+        if (a.sched != nullptr) {                 // dynamic tile draw: its own instantiation (see DYN above)
+            static VdaKernelDeviceState dyn_state;
+            const int ncu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED, BM, true>), smem, dyn_state);
+            if (ncu < 0) return 2;
+            hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED, BM, true>), dim3(ntiles < ncu ? (ntiles + 7) / 8 * 8 : ncu), dim3(NT), smem, s, a);
+            VDA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    static VdaKernelDeviceState dev_state;
+    const int num_cu = vda_prepare_kernel(reinterpret_cast<const void*>(&gemm8p_kernel<BN, AMODE, EPI, SCHED, BM, false>), smem, dev_state);
+    if (num_cu < 0) return 2;
     const int grid = ntiles < num_cu ? (ntiles + 7) / 8 * 8 : num_cu;     // one persistent workgroup per CU
-    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED, BM>), dim3(grid), dim3(NT), smem, s, a);
+    hipLaunchKernelGGL((gemm8p_kernel<BN, AMODE, EPI, SCHED, BM, false>), dim3(grid), dim3(NT), smem, s, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }

@@ -106,11 +106,41 @@ __device__ __forceinline__ vda_f32x2 gelu_erf2(vda_f32x2 x) {
 template <int N>
 __device__ __forceinline__ void gelu_erf_n(float (&v)[N]) {
     static_assert(N % 2 == 0, "pairs");
+    // The N / 2 pairs advance in LOCKSTEP, one polynomial step at a time: a packed-fp32 result cannot feed the next packed operation
+    // back to back (hipcc pads each dependent pair of v_pk_* with an s_nop), and written pair after pair the whole chain of a pair was
+    // emitted serially: 34 s_nop among 127 instructions per 8 outputs in the fc1 epilogue's ISA. In lockstep a pair's next step is
+    // N / 2 instructions away. Same IEEE operations in the same order per element: bit-identical to gelu_erf / gelu_erf2.
+    constexpr int P = N / 2;
+    vda_f32x2 ax[P], p[P], r[P];
+#define VDA_P2(c) vda_f32x2{c, c}
 #pragma unroll
-    for (int i = 0; i < N; i += 2) {
-        const vda_f32x2 r = gelu_erf2(vda_f32x2{v[i], v[i + 1]});
-        v[i] = r[0];
-        v[i + 1] = r[1];
+    for (int k = 0; k < P; ++k) ax[k] = vda_f32x2{fabsf(v[2 * k]), fabsf(v[2 * k + 1])};
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(VDA_P2(VDA_GELU_C6), ax[k], VDA_P2(VDA_GELU_C5));
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(p[k], ax[k], VDA_P2(VDA_GELU_C4));
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(p[k], ax[k], VDA_P2(VDA_GELU_C3));
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(p[k], ax[k], VDA_P2(VDA_GELU_C2));
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(p[k], ax[k], VDA_P2(VDA_GELU_C1));
+#pragma unroll
+    for (int k = 0; k < P; ++k) p[k] = __builtin_elementwise_fma(p[k], ax[k], VDA_P2(VDA_GELU_C0));
+#undef VDA_P2
+#pragma unroll
+    for (int k = 0; k < P; ++k) r[k] = vda_f32x2{__builtin_amdgcn_rcpf(p[k][0]), __builtin_amdgcn_rcpf(p[k][1])};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int k = 0; k < P; ++k) r[k] *= r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const vda_f32x2 relu = {fmaxf(v[2 * k], 0.f), fmaxf(v[2 * k + 1], 0.f)};
+        const vda_f32x2 o = __builtin_elementwise_fma(-ax[k], r[k], relu);
+        v[2 * k] = o[0];
+        v[2 * k + 1] = o[1];
     }
 }
 
@@ -164,6 +194,10 @@ struct VdaKernelDeviceState {
     unsigned long long done = 0;
     int num_cu[64] = {};
 };
+// Cap on the workgroups a persistent kernel launches (vda_set_max_wgs; 0 = one per CU). DIAGNOSTIC: two launch sequences that each
+// take HALF the chip were measured against two full-grid sequences interleaving freely (tools/two_stream.py, round 4): the capped
+// form loses (ViT-L 2 x 16 frames: 619 against 630 frames/s; two clips: 636 against 652), so nothing in the product sets it.
+extern int g_vda_max_wgs;
 inline int vda_prepare_kernel(const void* fn, int dyn_lds_bytes, VdaKernelDeviceState& st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -182,5 +216,6 @@ inline int vda_prepare_kernel(const void* fn, int dyn_lds_bytes, VdaKernelDevice
         st.num_cu[slot] = cu & ~7;
         st.done |= 1ull << slot;
     }
-    return st.num_cu[slot];
+    const int cap = g_vda_max_wgs;
+    return (cap >= 8 && cap < st.num_cu[slot]) ? (cap & ~7) : st.num_cu[slot];
 }
