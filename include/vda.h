@@ -179,6 +179,21 @@ int vda_layernorm_split_f16(const void* hi, const void* lo, void* out, const flo
 int vda_fold_ln_weight(const float* W, const float* bias, const float* ln_w, const float* ln_b, void* Wf, float* c1, float* c2,
                        int N, int K, vda_stream_t stream);
 
+/* ---- One block's MLP branch on the split residual stream in ONE kernel (dinov2_layers/mlp.py:35-41, block.py:105-106,
+ * layer_scale.py:27-28; fp16 path with the LayerNorm fold): hi + lo += gamma * (fc2(GELU(fc1(LayerNorm(hi + lo)))) + b2), hid never
+ * leaves the registers. Built for the widths vda_mlp_fused_supported(D, hidden) reports (D = 384, hidden = 1536: ViT-S).
+ *   hi_in  fp16 [M, D]   the A operand (the hi plane; may be `hi` itself: a workgroup reads and writes its own rows only)
+ *   stats  fp32 [M, 2]   (mean, rstd) of the LayerNorm in front of fc1 (vda_ln_stats_finalize); mean also re-centres the stream
+ *   w1, c1, c2           fc1 with the LayerNorm folded in: vda_fold_ln_weight's Wf [hidden, D], c1 [hidden], c2 [hidden]
+ *   w2p    fp16 [D, hidden]  fc2's weight with its hidden columns in the order vda_mlp_permute_w2_f16 gives them
+ *   b2, gamma fp32 [D]   fc2's bias, LayerScale
+ *   hi, lo fp16 [M, D]   the planes, updated in place;   part fp32 [D/64, stats_ld, 2]: partial row statistics (as VDA_EPI_SCALE_RES_SPLIT)
+ * Deterministic; a row's result does not depend on its position. */
+int vda_mlp_fused_supported(int D, int hidden);
+int vda_mlp_permute_w2_f16(const void* w2, void* w2p, int D, int hidden, vda_stream_t stream);
+int vda_mlp_fused_f16(const void* hi_in, const float* stats, const void* w1, const float* c1, const float* c2, const void* w2p, const float* b2,
+                      const float* gamma, void* hi, void* lo, float* part, int M, int D, int hidden, int stats_ld, vda_stream_t stream);
+
 /* pe = 'rope' (motion_module.py:254-257, motion_module/attention.py:403-429): channel pairs (2i, 2i+1) of the q and k thirds of the
  * fused projection qkv [T*hw, 3*C] (frame-major rows) rotated in place by  frame * 10000^(-2i/C)  (fp32 arithmetic, over the FULL
  * width C, before the head split); v is untouched. */
@@ -369,7 +384,9 @@ int vda_debug_occupy(int wgs, int lds_bytes, long long cycles, vda_stream_t stre
  * their output as fp16 and the residual add runs inside the following LayerNorm (vda_layernorm_residual_f32_f16); 0 = the add
  * is the GEMM's fp32 in-place epilogue (VDA_EPI_SCALE_RES_F32; measured 2 % faster end to end). Changes the workspace size.
  * "ln_fold" (default 1), "dyn_sched" (default 0): csrc/host.hip. "oc1_fused" (default 1; fp16 path): refinenet1's 2x upsample is
- * evaluated inside output_conv1 (vda_conv3x3_up2_f16) and path_1 never exists at full size; 0 = vda_bilinear_nhwc + the conv. */
+ * evaluated inside output_conv1 (vda_conv3x3_up2_f16) and path_1 never exists at full size; 0 = vda_bilinear_nhwc + the conv.
+ * "mlp_fused" (default 0; fp16 path with ln_fold, widths vda_mlp_fused_supported reports): 1 = a block's fc1 + GELU + fc2 + residual
+ * run as vda_mlp_fused_f16 instead of the two GEMM launches (measured slower on the MI355X: kept as a tested option). */
 int vda_set_option(vda_model* h, const char* name, int value);
 /* Measurement hook (bench.py): from vda_profile_start until vda_profile_stop every `every`-th GEMM / conv launch of each
  * (shape, epilogue) inside vda_forward is bracketed by two events on the launch stream. vda_profile_stop waits for them and

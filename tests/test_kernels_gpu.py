@@ -916,3 +916,72 @@ def test_conv3x3_fused_upsample_at_the_benchmarked_grid(ops):
         upf = F.interpolate(x[f:f + 1].permute(0, 3, 1, 2).float(), size=(H, H), mode="bilinear", align_corners=True).to(F16).float()
         ref = F.conv2d(upf, wt.to(F16).float(), b, padding=1).permute(0, 2, 3, 1)
         close(out[f:f + 1], ref, what=f"fused output_conv1, frame {f}")
+
+
+@pytest.mark.parametrize("M", [43840, 128 * 3 + 37, 50])
+def test_mlp_fused_against_the_unfused_pair_and_fp32(ops, M):
+    """vda_mlp_fused_f16 (ViT-S widths): x += gamma * (fc2(GELU(fc1(LayerNorm(x)))) + b2) on the split stream in one kernel, hid kept in
+    registers (mlp.py:35-41, block.py:105-106). Against (a) the fp32 definition on sampled rows and (b) the unfused pair of GEMM
+    launches it replaces (VDA_EPI_LN_GELU_F16 then VDA_EPI_SCALE_RES_SPLIT) on every row: planes to fp16-GEMM accuracy, partial
+    statistics consistent with the planes it wrote. M = 43 840 is the benchmarked clip (256 full workgroups + 173 half ones), the small
+    sizes have a ragged last workgroup / fewer rows than one workgroup."""
+    from video_depth_anything_amd import _lib
+    lib = _lib.lib
+    D, H = 384, 1536
+    assert lib.vda_mlp_fused_supported(D, H) == 1 and lib.vda_mlp_fused_supported(1024, 4096) == 0
+    x = rnd(M, D, seed=300, scale=1.5) + rnd(M, 1, seed=301) * 3.0                       # rows with their own offsets
+    mean = x.mean(1, keepdim=True)
+    xc = x - mean * 0.9                                                                   # the stream is kept NEAR each row's mean, not on it
+    hi0, lo0 = xc.to(F16), (xc - xc.to(F16).float()).to(F16)
+    s = hi0.float() + lo0.float()
+    mu, var = s.mean(1), s.var(1, unbiased=False)
+    stats = torch.stack([mu, (var + 1e-6).rsqrt()], 1).contiguous()
+    W1, b1 = rnd(H, D, seed=302, scale=D ** -0.5), rnd(H, seed=303, scale=0.1)
+    lnw, lnb = 1.0 + rnd(D, seed=304, scale=0.1), rnd(D, seed=305, scale=0.1)
+    W2, b2 = rnd(D, H, seed=306, scale=H ** -0.5), rnd(D, seed=307, scale=0.1)
+    gamma = rnd(D, seed=308).abs() + 0.5
+    Wf, c1, c2 = torch.empty(H, D, dtype=F16, device="cuda"), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
+    ops.fold_ln_weight(dev(W1), dev(b1), dev(lnw), dev(lnb), Wf, c1, c2, H, D)
+    W2h = dev(W2.to(F16))
+    W2p = torch.empty_like(W2h)
+    ops.mlp_permute_w2(W2h, W2p, D, H)
+    # (the permutation is what the header says: inside every 32 hidden units, position 8 g + t holds unit 16 (t >> 2) + 4 g + (t & 3))
+    k = torch.arange(H)
+    src = (k // 32) * 32 + 16 * ((k % 8) // 4) + 4 * ((k // 8) % 4) + (k % 4)
+    assert torch.equal(W2p.cpu(), W2h.cpu()[:, src])
+
+    def planes():
+        return dev(hi0), dev(lo0), torch.full((D // 64, M, 2), float("nan"), device="cuda")
+
+    hi, lo, part = planes()
+    ops.mlp_fused(hi, dev(stats), Wf, c1, c2, W2p, dev(b2), dev(gamma), hi, lo, part, M, D, H)
+    hi2, lo2, part2 = planes()
+    hid = torch.empty(M, H, dtype=F16, device="cuda")
+    ops.gemm(hi2, Wf, hid, _lib.EPI_LN_GELU_F16, M=M, N=H, K=D, bias=c2, gamma=c1, stats=dev(stats))
+    ops.gemm(hid, W2h, hi2, _lib.EPI_SCALE_RES_SPLIT, M=M, N=D, K=H, bias=dev(b2), gamma=dev(gamma), res=hi2, res2=lo2, out2=lo2, stats=part2, pos=dev(stats))
+    got, two = hi.float() + lo.float(), hi2.float() + lo2.float()
+    assert torch.isfinite(got).all() and torch.isfinite(part).all()
+    # (a) fp32 definition on sampled rows
+    sel = torch.arange(0, M, max(1, M // 300))
+    xs = s[sel]
+    ln = (xs - xs.mean(1, keepdim=True)) * (xs.var(1, unbiased=False, keepdim=True) + 1e-6).rsqrt() * lnw + lnb
+    ref = xs - mu[sel, None] + gamma * (torch.nn.functional.gelu(ln @ W1.t() + b1) @ W2.t() + b2)
+    e_f = float((got[sel.cuda()].cpu() - ref).abs().mean() / ref.abs().mean())
+    e_u = float((two[sel.cuda()].cpu() - ref).abs().mean() / ref.abs().mean())
+    assert e_f < 1.5e-3 and e_f < 1.3 * e_u + 1e-4, (e_f, e_u)
+    # (b) every row against the unfused pair (same operands, different summation order)
+    assert float((got - two).abs().max()) < 3e-2 and float((got - two).abs().mean() / two.abs().mean()) < 4e-4
+    # partial statistics describe the planes the kernel wrote
+    blocks = got.view(M, D // 64, 64)
+    assert torch.allclose(part[..., 0].t(), blocks.sum(2), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(part[..., 1].t(), ((blocks - blocks.mean(2, keepdim=True)) ** 2).sum(2), rtol=2e-3, atol=2e-3)
+    # deterministic, and a row's result does not depend on where it sits (rows 0.. of a second call shifted by 16 rows)
+    hi3, lo3, part3 = planes()
+    ops.mlp_fused(hi3, dev(stats), Wf, c1, c2, W2p, dev(b2), dev(gamma), hi3, lo3, part3, M, D, H)
+    assert torch.equal(hi3, hi) and torch.equal(lo3, lo) and torch.equal(part3, part)
+    if M > 200:
+        sh = 144
+        hi4, lo4 = dev(hi0[sh:]), dev(lo0[sh:])
+        part4 = torch.empty(D // 64, M - sh, 2, device="cuda")
+        ops.mlp_fused(hi4, dev(stats[sh:]), Wf, c1, c2, W2p, dev(b2), dev(gamma), hi4, lo4, part4, M - sh, D, H)
+        assert torch.equal(hi4, hi[sh:]) and torch.equal(lo4, lo[sh:])

@@ -59,6 +59,9 @@ SIGNATURES = {
     "vda_ln_stats_finalize": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp]),
     "vda_layernorm_split_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp]),
     "vda_fold_ln_weight": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "vda_mlp_fused_supported": (_i, [_i, _i]),
+    "vda_mlp_permute_w2_f16": (_i, [_vp, _vp, _i, _i, _vp]),
+    "vda_mlp_fused_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_groupnorm_nhwc_f16": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_groupnorm_nhwc_f32": (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _i, _vp]),
     "vda_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
 PER_FILE = {"stitch.hip": ["-ffp-contract=off"]}
 # attention: the softmax row sums are 32 scalar fp32 adds per tile; SLP packs 22 of them into v_pk_add_f32, which costs several
 # times two v_add_f32 next to MFMAs (MI355X_MICROARCH.md, "price of one filler") in a loop that is VALU-bound.
-PER_PREFIX = {"gemm": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"],
+PER_PREFIX = {"gemm": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"], "mlp_fused.hip": ["-fno-slp-vectorize"],
               # the dynamic tile draw of gemm8p_kernel.h must stay a plain returning atomic (see the comment there)
               "gemm8p": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 

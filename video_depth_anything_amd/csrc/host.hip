@@ -162,6 +162,8 @@ struct vda_model {
                                               // processes that share the GPU with communication kernels (multi-rank runs turn it on)
     int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
     int oc1_fused = 1;                        // vda_set_option("oc1_fused"): refinenet1's 2x upsample folded into output_conv1 (fp16 path)
+    int mlp_fused = 0;                        // vda_set_option("mlp_fused"): fc1 + GELU + fc2 + residual in one kernel where built (D = 384; needs ln_fold).
+                                              // OFF: measured slower than the two GEMM launches (ViT-S clip 8.69 -> 9.00 ms, mlp_fused.hip's header)
     // Split-stream overflow reports (ln_fold): each forward's device flag is copied, at its end and on its stream, into the next
     // word of this pinned ring; vda_forward_status / the next vda_forward read the words whose forwards have completed.
     static constexpr int OVF_RING = 16;
@@ -385,6 +387,12 @@ int pack_all(vda_model* h, int prec) {
                 h->vec[k + lk + ".c2"] = (float*)c2;
                 VDA_TRY(vda_fold_ln_weight(raw(b + lk + ".weight"), raw(b + lk + ".bias"), raw(b + nk + ".weight"), raw(b + nk + ".bias"), d, (float*)c1,
                                            (float*)c2, outs[j], D, s));
+            }
+            // the fused MLP kernel (vda_mlp_fused_f16; widths it is built for) takes fc2's weight with its hidden columns permuted
+            if (vda_mlp_fused_supported(D, 4 * D)) {
+                T* d = nullptr;
+                VDA_TRY(mat(k + "mlp.fc2.weight.perm", (size_t)D * 4 * D, &d));
+                VDA_TRY(vda_mlp_permute_w2_f16(h->mat[prec].at(k + "mlp.fc2.weight"), d, D, 4 * D, s));
             }
         }
     }
@@ -725,7 +733,7 @@ struct Run {
         void* xn = act("xn", (size_t)rows * D);
         void* qkv = act("qkv", (size_t)rows * 3 * D);
         void* ao = act("ao", (size_t)rows * D);
-        void* hid = act("hid", (size_t)rows * 4 * D);
+        void* hid = nullptr;                     // (allocated below, unless the fused MLP kernel makes it unnecessary)
         void* taps[4] = {nullptr, nullptr, nullptr, nullptr};
         int ntap = 0;
         // Residual add of a block's two projections (attn.proj, mlp.fc2). Default: the GEMM's own fp32 in-place epilogue
@@ -739,6 +747,10 @@ struct Run {
         // per-row partial statistics); qkv / fc1 take the hi plane as their A operand with LayerNorm's affine folded into their
         // weights and apply rstd * (acc - mean * c1) + c2 in their epilogue (VDA_EPI_LN_*). Only the four taps still run a LayerNorm.
         const bool fold = prec == VDA_PREC_F16 && h->ln_fold != 0 && !defer && D % 64 == 0;
+        // mlp.py:35-41 + block.py:106: the whole MLP branch in one kernel where vda_mlp_fused_f16 is built for the width (ViT-S): hid
+        // stays in registers, one launch instead of two. An OPTION, off by default: in-process A/B it loses to the two launches.
+        const bool mlp1 = fold && h->mlp_fused != 0 && vda_mlp_fused_supported(D, 4 * D) != 0;
+        if (!mlp1) hid = act("hid", (size_t)rows * 4 * D);
         void* thi = fold ? buf("tok_hi", (size_t)rows * D, 2) : nullptr;
         void* tlo = fold ? buf("tok_lo", (size_t)rows * D, 2) : nullptr;
         float* lnpart = fold ? f32("ln_part", (size_t)rows * (D / 64) * 2) : nullptr;
@@ -800,14 +812,22 @@ struct Run {
                 VDA_TRY(dense(ao, W(k + "attn.proj.weight"), tok, VDA_EPI_SCALE_RES_F32, rows, D, D, V(k + "attn.proj.bias"), tok, V(k + "ls1.gamma")));
                 VDA_TRY(layernorm(tok, xn, V(k + "norm2.weight"), V(k + "norm2.bias"), ENC_LN_EPS, rows, D));
             }
-            if (fold) VDA_TRY(ln_gemm(k + "mlp.fc1", hid, VDA_EPI_LN_GELU_F16, 4 * D));
+            if (mlp1) {
+                if (!dry)
+                    VDA_TRY(vda_mlp_fused_f16(thi, lnstat, W(k + "mlp.fc1.weight.ln"), V(k + "mlp.fc1.c1"), V(k + "mlp.fc1.c2"), W(k + "mlp.fc2.weight.perm"),
+                                              V(k + "mlp.fc2.bias"), V(k + "ls2.gamma"), thi, tlo, lnpart, rows, D, 4 * D, rows, s));
+            } else if (fold) VDA_TRY(ln_gemm(k + "mlp.fc1", hid, VDA_EPI_LN_GELU_F16, 4 * D));
             else VDA_TRY(dense(xn, W(k + "mlp.fc1.weight"), hid, VDA_EPI_BIAS_GELU_F16, rows, 4 * D, D, V(k + "mlp.fc1.bias")));
             bool is_tap = false;
             for (int t = 0; t < 4; ++t) is_tap = is_tap || c.taps[t] == i;
             const bool last = i + 1 == c.depth;
             void* tp = (is_tap && ntap < 4) ? act("tap" + std::to_string(ntap), (size_t)BT * P * D) : nullptr;
             if (fold) {
-                VDA_TRY(res_gemm(hid, k + "mlp.fc2", k + "ls2.gamma", 4 * D, !last));
+                if (mlp1) {
+                    if (!dry) VDA_TRY(vda_ln_stats_finalize(lnpart, lnstat, ENC_LN_EPS, rows, D / 64, ovf, s));
+                } else {
+                    VDA_TRY(res_gemm(hid, k + "mlp.fc2", k + "ls2.gamma", 4 * D, !last));
+                }
                 if (tp != nullptr) VDA_TRY(tap_ln(tp, Nt, 1));                                             // final norm, cls dropped
             } else if (defer) {
                 VDA_TRY(dense(hid, W(k + "mlp.fc2.weight"), yb, VDA_EPI_BIAS_F16, rows, D, 4 * D, V(k + "mlp.fc2.bias")));
@@ -1177,7 +1197,7 @@ static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_
 }
 
 // Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1), "dyn_sched" (default 0), "oc1_fused"
-// (default 1): see Run::forward.
+// (default 1), "mlp_fused" (default 0): see Run::forward.
 extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     VDA_REQUIRE(h && name, "vda_set_option: null argument");
     if (strcmp(name, "residual_in_ln") == 0) {
@@ -1197,6 +1217,11 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     if (strcmp(name, "ln_fold") == 0) {
         h->ln_fold = value;
         h->layouts.clear();
+        return 0;
+    }
+    if (strcmp(name, "mlp_fused") == 0) {
+        h->mlp_fused = value != 0;
+        h->layouts.clear();                  // hid is not allocated with it
         return 0;
     }
     if (strcmp(name, "oc1_fused") == 0) {

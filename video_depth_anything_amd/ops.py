@@ -156,6 +156,22 @@ def fold_ln_weight(W, bias, ln_w, ln_b, Wf, c1, c2, N, K):
     check(lib.vda_fold_ln_weight(_p(W), _p(bias), _p(ln_w), _p(ln_b), _p(Wf), _p(c1), _p(c2), N, K, _stream(W)), "vda_fold_ln_weight")
 
 
+def mlp_permute_w2(w2, w2p, D, hidden):
+    """fc2's weight [D, hidden] with its hidden columns in the order the fused MLP kernel's register-resident activations have."""
+    _req(w2, F16, "w2"), _req(w2p, F16, "w2p")
+    check(lib.vda_mlp_permute_w2_f16(_p(w2), _p(w2p), D, hidden, _stream(w2)), "vda_mlp_permute_w2_f16")
+
+
+def mlp_fused(hi_in, stats, w1, c1, c2, w2p, b2, gamma, hi, lo, part, M, D, hidden, stats_ld=None):
+    """hi + lo += gamma * (fc2(GELU(fc1(LayerNorm(hi + lo)))) + b2) in one kernel (vda_mlp_fused_f16: see include/vda.h)."""
+    for t, n in ((hi_in, "hi_in"), (w1, "w1"), (w2p, "w2p"), (hi, "hi"), (lo, "lo")):
+        _req(t, F16, n)
+    for t, n in ((stats, "stats"), (c1, "c1"), (c2, "c2"), (b2, "b2"), (gamma, "gamma"), (part, "part")):
+        _req(t, F32, n)
+    check(lib.vda_mlp_fused_f16(_p(hi_in), _p(stats), _p(w1), _p(c1), _p(c2), _p(w2p), _p(b2), _p(gamma), _p(hi), _p(lo), _p(part), M, D, hidden,
+                                M if stats_ld is None else stats_ld, _stream(hi)), "vda_mlp_fused_f16")
+
+
 def layernorm(x, out, w, b, eps, rows, D, group=0, skip=0, pe=None, pe_rows_per_step=0, pe_steps=0):
     _req(x, F32, "x"), _act(out, "out"), _req(w, F32, "w"), _req(b, F32, "b"), _req(pe, F32, "pe")
     fn = lib.vda_layernorm_f32_f32 if out.dtype == F32 else lib.vda_layernorm_f32_f16
