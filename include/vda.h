@@ -386,7 +386,9 @@ int vda_debug_occupy(int wgs, int lds_bytes, long long cycles, vda_stream_t stre
  * "ln_fold" (default 1), "dyn_sched" (default 0): csrc/host.hip. "oc1_fused" (default 1; fp16 path): refinenet1's 2x upsample is
  * evaluated inside output_conv1 (vda_conv3x3_up2_f16) and path_1 never exists at full size; 0 = vda_bilinear_nhwc + the conv.
  * "mlp_fused" (default 0; fp16 path with ln_fold, widths vda_mlp_fused_supported reports): 1 = a block's fc1 + GELU + fc2 + residual
- * run as vda_mlp_fused_f16 instead of the two GEMM launches (measured slower on the MI355X: kept as a tested option). */
+ * run as vda_mlp_fused_f16 instead of the two GEMM launches (measured slower on the MI355X: kept as a tested option).
+ * "head_overlap" (default 0): 1 = the part of the head that needs taps 0..2 only (dpt_temporal.py:55-69 for i < 3, :75, :78-80) runs
+ * on a side stream of the handle as soon as tap 2 exists, under the remaining encoder blocks; bit-identical results. */
 int vda_set_option(vda_model* h, const char* name, int value);
 /* Measurement hook (bench.py): from vda_profile_start until vda_profile_stop every `every`-th GEMM / conv launch of each
  * (shape, epilogue) inside vda_forward is bracketed by two events on the launch stream. vda_profile_stop waits for them and

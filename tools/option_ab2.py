@@ -12,6 +12,9 @@ m = VideoDepthAnything(encoder=enc, features=cfg.features, out_channels=list(cfg
 m.load_state_dict(synthetic_state_dict(cfg, seed=0)); m = m.to("cuda")
 x = torch.randn(1, 32, 3, 518, 518, generator=torch.Generator().manual_seed(0)).cuda()
 ts = {v: [] for v in vals}; outs = {}
+side = torch.cuda.Stream() if os.environ.get("AB_STREAM") == "1" else None          # AB_STREAM=1: a non-default stream, as infer_video_depth's lanes
+if side is not None:
+    torch.cuda.set_stream(side)
 for rep in range(7):
     for v in vals:
         m.engine.set_option(opt, v)

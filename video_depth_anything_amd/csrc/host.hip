@@ -162,6 +162,14 @@ struct vda_model {
                                               // processes that share the GPU with communication kernels (multi-rank runs turn it on)
     int ln_fold = VDA_LN_FOLD_DEFAULT;        // vda_set_option("ln_fold"): LayerNorm folded into the encoder GEMMs either side of it (fp16 path)
     int oc1_fused = 1;                        // vda_set_option("oc1_fused"): refinenet1's 2x upsample folded into output_conv1 (fp16 path)
+    int head_overlap = 0;                     // vda_set_option("head_overlap"): the head's tap-0..2 work on a side stream under the last encoder blocks.
+                                              // OFF: in-process A/B the sign depends on the box (+0.8 % ViT-L / +1.5 % ViT-S on a 52.1 ms box,
+                                              // -0.3 .. -0.5 % on a 50.0 ms box; two clips in flight -0.4 %), profiles/r04/head_overlap_ab.txt
+    struct Side {
+        hipStream_t stream = nullptr;
+        hipEvent_t fork = nullptr, join = nullptr;
+    };
+    std::map<hipStream_t, Side> sides;        // one side stream + event pair per caller stream (two forwards may be in flight on two)
     int mlp_fused = 0;                        // vda_set_option("mlp_fused"): fc1 + GELU + fc2 + residual in one kernel where built (D = 384; needs ln_fold).
                                               // OFF: measured slower than the two GEMM launches (ViT-S clip 8.69 -> 9.00 ms, mlp_fused.hip's header)
     // Split-stream overflow reports (ln_fold): each forward's device flag is copied, at its end and on its stream, into the next
@@ -793,6 +801,49 @@ struct Run {
             return vda_layernorm_residual_f32_f16(tok, yb, gamma, out, w, b, ENC_LN_EPS, rows, D, group, skip, s);
         };
         bool xn_ready = false;                 // norm1 of block i already ran (fused with block i-1's fc2 residual)
+        // ---- the part of the head that needs taps 0..2 only (dpt_temporal.py:55-69 for i = 0, 1, 2; :75 motion module 0 on layer_3;
+        // :78-80 layer{1,2,3}_rn): 3.8 of the head's 12.5 TFLOP at ViT-L. Option head_overlap runs it on a SIDE stream as soon as tap 2
+        // exists, under the remaining encoder blocks (ViT-L: blocks 18-23), so that its kernels fill the tail rounds and epilogue
+        // bursts of theirs - what two clips in flight do for a video, inside ONE clip. Same kernels, same arithmetic: bit-identical.
+        const int* ocp = h->ocp;
+        const int Fe = c.features, Fhp = h->Fhp;
+        const int h1 = 4 * ph, w1 = 4 * pw, h2 = 2 * ph, w2 = 2 * pw, h4 = (ph - 1) / 2 + 1, w4 = (pw - 1) / 2 + 1;
+        void *l1r = nullptr, *l2r = nullptr, *l3r = nullptr;
+        auto head_early = [&]() -> int {
+            void* t0 = act("t0", (size_t)BT * P * ocp[0]);
+            VDA_TRY(dense(taps[0], W("proj0.w"), t0, VDA_EPI_BIAS_F16, BT * P, ocp[0], D, V("proj0.b")));
+            void* l1 = act("l1", (size_t)BT * h1 * w1 * ocp[0]);
+            {
+                vda_gemm_args a = {};
+                a.A = t0, a.W = W("resize0.w"), a.out = l1, a.bias = V("resize0.b");
+                a.M = BT * P, a.N = 16 * ocp[0], a.K = ocp[0], a.ldc = ocp[0], a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_CONVT_F16;
+                a.tK = 4, a.tH = ph, a.tW = pw, a.tCout = ocp[0];
+                VDA_TRY(gemm(a));
+            }
+            void* t1 = act("t1", (size_t)BT * P * ocp[1]);
+            VDA_TRY(dense(taps[1], W("proj1.w"), t1, VDA_EPI_BIAS_F16, BT * P, ocp[1], D, V("proj1.b")));
+            void* l2 = act("l2", (size_t)BT * h2 * w2 * ocp[1]);
+            {
+                vda_gemm_args a = {};
+                a.A = t1, a.W = W("resize1.w"), a.out = l2, a.bias = V("resize1.b");
+                a.M = BT * P, a.N = 4 * ocp[1], a.K = ocp[1], a.ldc = ocp[1], a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_CONVT_F16;
+                a.tK = 2, a.tH = ph, a.tW = pw, a.tCout = ocp[1];
+                VDA_TRY(gemm(a));
+            }
+            void* l3 = act("l3", (size_t)BT * P * ocp[2]);
+            VDA_TRY(dense(taps[2], W("proj2.w"), l3, VDA_EPI_BIAS_F16, BT * P, ocp[2], D, V("proj2.b")));
+            void* l3t = nullptr;
+            VDA_TRY(temporal(0, l3, B, T, P, ocp[2], "l3t", &l3t));                  // dpt_temporal.py:75
+            l1r = act("l1r", (size_t)BT * h1 * w1 * Fe);
+            VDA_TRY(conv3x3(l1, "rn1.w", l1r, BT, h1, w1, ocp[0], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
+            l2r = act("l2r", (size_t)BT * h2 * w2 * Fe);
+            VDA_TRY(conv3x3(l2, "rn2.w", l2r, BT, h2, w2, ocp[1], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
+            l3r = act("l3r", (size_t)BT * P * Fe);
+            VDA_TRY(conv3x3(l3t, "rn3.w", l3r, BT, ph, pw, ocp[2], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
+            return 0;
+        };
+        bool early_done = false;
+        vda_model::Side* side = nullptr;
         for (int i = 0; i < c.depth; ++i) {
             const std::string k = "b" + std::to_string(i) + ".";
             if (fold) {
@@ -857,53 +908,47 @@ struct Run {
                     VDA_TRY(dense(cat, W(kr + ".w"), tp, VDA_EPI_BIAS_GELU_F16, BT * P, D, 2 * D, V(kr + ".b")));
                 }
                 taps[ntap++] = tp;
+                if (ntap == 3 && !last && !early_done) {
+                    if (dry || !h->head_overlap) {
+                        // (dry pass: the buffers are requested here so that both orders of execution find them laid out)
+                        if (dry) {
+                            VDA_TRY(head_early());
+                            early_done = true;
+                        }
+                    } else {
+                        vda_model::Side& sd = h->sides[s];
+                        if (sd.stream == nullptr) {
+                            VDA_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
+                            VDA_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
+                            VDA_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+                        }
+                        side = &sd;
+                        VDA_HIP(hipEventRecord(sd.fork, s));               // taps 0..2 are behind this point of the caller's stream
+                        VDA_HIP(hipStreamWaitEvent(sd.stream, sd.fork, 0));
+                        hipStream_t main_stream = s;
+                        s = sd.stream;
+                        const int rc = head_early();
+                        s = main_stream;
+                        if (rc != 0) return rc;
+                        VDA_HIP(hipEventRecord(sd.join, sd.stream));
+                        early_done = true;
+                    }
+                }
             }
         }
         if (ntap != 4) {
             vda_set_error("vda_forward: the configuration's taps are not four distinct block indices below depth");
             return 1;
         }
-        // ---- head: reassemble (dpt_temporal.py:55-69)
-        const int* ocp = h->ocp;
-        const int Fe = c.features, Fhp = h->Fhp;
-        const int h1 = 4 * ph, w1 = 4 * pw, h2 = 2 * ph, w2 = 2 * pw, h4 = (ph - 1) / 2 + 1, w4 = (pw - 1) / 2 + 1;
-        void* t0 = act("t0", (size_t)BT * P * ocp[0]);
-        VDA_TRY(dense(taps[0], W("proj0.w"), t0, VDA_EPI_BIAS_F16, BT * P, ocp[0], D, V("proj0.b")));
-        void* l1 = act("l1", (size_t)BT * h1 * w1 * ocp[0]);
-        {
-            vda_gemm_args a = {};
-            a.A = t0, a.W = W("resize0.w"), a.out = l1, a.bias = V("resize0.b");
-            a.M = BT * P, a.N = 16 * ocp[0], a.K = ocp[0], a.ldc = ocp[0], a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_CONVT_F16;
-            a.tK = 4, a.tH = ph, a.tW = pw, a.tCout = ocp[0];
-            VDA_TRY(gemm(a));
-        }
-        void* t1 = act("t1", (size_t)BT * P * ocp[1]);
-        VDA_TRY(dense(taps[1], W("proj1.w"), t1, VDA_EPI_BIAS_F16, BT * P, ocp[1], D, V("proj1.b")));
-        void* l2 = act("l2", (size_t)BT * h2 * w2 * ocp[1]);
-        {
-            vda_gemm_args a = {};
-            a.A = t1, a.W = W("resize1.w"), a.out = l2, a.bias = V("resize1.b");
-            a.M = BT * P, a.N = 4 * ocp[1], a.K = ocp[1], a.ldc = ocp[1], a.a_mode = VDA_A_DENSE, a.epilogue = VDA_EPI_CONVT_F16;
-            a.tK = 2, a.tH = ph, a.tW = pw, a.tCout = ocp[1];
-            VDA_TRY(gemm(a));
-        }
-        void* l3 = act("l3", (size_t)BT * P * ocp[2]);
-        VDA_TRY(dense(taps[2], W("proj2.w"), l3, VDA_EPI_BIAS_F16, BT * P, ocp[2], D, V("proj2.b")));
+        // ---- head: reassemble (dpt_temporal.py:55-69), temporal modules on layer_3 / layer_4 (:75-76), layer_rn (:78-81)
+        if (!early_done) VDA_TRY(head_early());
+        else if (side != nullptr) VDA_HIP(hipStreamWaitEvent(s, side->join, 0));     // the side stream's part is done before anything reads it
         void* t3 = act("t3", (size_t)BT * P * ocp[3]);
         VDA_TRY(dense(taps[3], W("proj3.w"), t3, VDA_EPI_BIAS_F16, BT * P, ocp[3], D, V("proj3.b")));
         void* l4 = act("l4", (size_t)BT * h4 * w4 * ocp[3]);
         VDA_TRY(conv3x3(t3, "resize3.w", l4, BT, ph, pw, ocp[3], ocp[3], VDA_EPI_BIAS_F16, 2, V("resize3.b")));
-        // ---- temporal modules on layer_3 / layer_4 (dpt_temporal.py:75-76)
-        void *l3t = nullptr, *l4t = nullptr;
-        VDA_TRY(temporal(0, l3, B, T, P, ocp[2], "l3t", &l3t));
+        void* l4t = nullptr;
         VDA_TRY(temporal(1, l4, B, T, h4 * w4, ocp[3], "l4t", &l4t));
-        // ---- layer_rn (no bias) and the fusion pyramid (dpt_temporal.py:78-91)
-        void* l1r = act("l1r", (size_t)BT * h1 * w1 * Fe);
-        VDA_TRY(conv3x3(l1, "rn1.w", l1r, BT, h1, w1, ocp[0], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
-        void* l2r = act("l2r", (size_t)BT * h2 * w2 * Fe);
-        VDA_TRY(conv3x3(l2, "rn2.w", l2r, BT, h2, w2, ocp[1], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
-        void* l3r = act("l3r", (size_t)BT * P * Fe);
-        VDA_TRY(conv3x3(l3t, "rn3.w", l3r, BT, ph, pw, ocp[2], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
         void* l4r = act("l4r", (size_t)BT * h4 * w4 * Fe);
         VDA_TRY(conv3x3(l4t, "rn4.w", l4r, BT, h4, w4, ocp[3], Fe, VDA_EPI_BIAS_F16, 1, nullptr));
         void *p4 = nullptr, *p4t = nullptr, *p3 = nullptr, *p3t = nullptr, *p2 = nullptr, *p1 = nullptr;
@@ -1022,6 +1067,11 @@ extern "C" int vda_create(const vda_config* cfg, vda_model** out) {
 extern "C" int vda_destroy(vda_model* h) {
     if (h == nullptr) return 0;
     if (h->ovf_host) (void)hipHostFree((void*)h->ovf_host);
+    for (auto& kv : h->sides) {
+        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
+        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
+        if (kv.second.stream) (void)hipStreamDestroy(kv.second.stream);
+    }
     for (void* p : h->owned) (void)hipFree(p);
     delete h;
     return 0;
@@ -1197,7 +1247,7 @@ static int vda_debug_copy_impl(vda_model* h, const char* name, void* dst, int64_
 }
 
 // Tuning / A-B switches of the launch sequence: "residual_in_ln" (default 0), "ln_fold" (default 1), "dyn_sched" (default 0), "oc1_fused"
-// (default 1), "mlp_fused" (default 0): see Run::forward.
+// (default 1), "mlp_fused" (default 0), "head_overlap" (default 0): see Run::forward.
 extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     VDA_REQUIRE(h && name, "vda_set_option: null argument");
     if (strcmp(name, "residual_in_ln") == 0) {
@@ -1217,6 +1267,10 @@ extern "C" int vda_set_option(vda_model* h, const char* name, int value) {
     if (strcmp(name, "ln_fold") == 0) {
         h->ln_fold = value;
         h->layouts.clear();
+        return 0;
+    }
+    if (strcmp(name, "head_overlap") == 0) {
+        h->head_overlap = value != 0;
         return 0;
     }
     if (strcmp(name, "mlp_fused") == 0) {

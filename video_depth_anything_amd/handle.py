@@ -46,6 +46,8 @@ class ModelHandle:
             _check(lib.vda_set_option(h, b"residual_in_ln", int(os.environ["VDA_RESIDUAL_IN_LN"])), "vda_set_option")
         if os.environ.get("VDA_DYN_SCHED") is not None:
             _check(lib.vda_set_option(h, b"dyn_sched", int(os.environ["VDA_DYN_SCHED"])), "vda_set_option")
+        if os.environ.get("VDA_HEAD_OVERLAP") is not None:
+            _check(lib.vda_set_option(h, b"head_overlap", int(os.environ["VDA_HEAD_OVERLAP"])), "vda_set_option")
         if os.environ.get("VDA_LN_FOLD") is not None:
             _check(lib.vda_set_option(h, b"ln_fold", int(os.environ["VDA_LN_FOLD"])), "vda_set_option")
         self.loaded = False
