@@ -321,7 +321,7 @@ def main():
         # HBM bytes per launch of that kernel: cannot be read live (needs rocprofv3 --pmc passes); taken from the
         # committed PMC summary of the same command (tools/pmc_bench.sh -> profiles/), null when absent.
         traffic = None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", rnd, f"{args.encoder}_pmc_hbm_traffic.json")
             if os.path.exists(pmc) and not args.fp32:
                 traffic = json.load(open(pmc))["kernels"].get(dom, {}).get("hbm_bytes_per_launch")

@@ -511,7 +511,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
             const int rc192 = vda_gemm8p_dense_bn256_bm192(a8, s);
             if (rc192 >= 0) {
                 static thread_local char name192[64];
-                snprintf(name192, sizeof(name192), "gemm8p_kernel<256, %d, %d, 1, 192>", a.a_mode, a.epilogue);
+                snprintf(name192, sizeof(name192), "gemm8p_kernel<256, %d, %d, 1, 192, %s>", a.a_mode, a.epilogue, a.sched ? "true" : "false");
                 g_last_kernel = name192;
                 return rc192;
             }
@@ -528,7 +528,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
             const int rc384 = vda_gemm256s_dense_bn384_bm192(a8, s);
             if (rc384 >= 0) {
                 static thread_local char name384[64];
-                snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192>", a.a_mode, a.epilogue);
+                snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192, 1>", a.a_mode, a.epilogue);
                 g_last_kernel = name384;
                 return rc384;
             }
@@ -546,7 +546,7 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
             const int rc192 = vda_gemm256s_dense_bn128_bm192(a8, s);
             if (rc192 >= 0) {
                 static thread_local char name192[64];
-                snprintf(name192, sizeof(name192), "gemm256s_kernel<128, %d, %d, 192>", a.a_mode, a.epilogue);
+                snprintf(name192, sizeof(name192), "gemm256s_kernel<128, %d, %d, 192, 1>", a.a_mode, a.epilogue);
                 g_last_kernel = name192;
                 return rc192;
             }
@@ -558,8 +558,11 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
         if (rc >= 0) {
             // exact instantiation name as rocprofv3 prints it: gemm256[s]_kernel<BN, a_mode, epilogue> / gemm8p_kernel<...>
             static thread_local char name[64];
-            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d, %d, 256>", big, a.a_mode, a.epilogue, sched8 == 1 ? 0 : sched8 == 2 ? 2 : 1);
-            else snprintf(name, sizeof(name), "gemm256%s_kernel<%d, %d, %d>", small_mfma ? "s" : "", big, a.a_mode, a.epilogue);
+            // (every template argument, defaults included, as the profiler prints them)
+            const int sch = sched8 == 1 ? 0 : sched8 == 2 ? 2 : 1;
+            if (eight) snprintf(name, sizeof(name), "gemm8p_kernel<%d, %d, %d, %d, 256, %s>", big, a.a_mode, a.epilogue, sch, (a.sched && sch == 1) ? "true" : "false");
+            else if (small_mfma) snprintf(name, sizeof(name), "gemm256s_kernel<%d, %d, %d, 256, 1>", big, a.a_mode, a.epilogue);
+            else snprintf(name, sizeof(name), "gemm256_kernel<%d, %d, %d>", big, a.a_mode, a.epilogue);
             g_last_kernel = name;
             return rc;
         }                                   // -1: pair not built for the large tile, use the 128-row kernel
