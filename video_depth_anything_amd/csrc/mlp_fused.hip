@@ -38,14 +38,16 @@
 namespace {
 
 constexpr int D = 384, HID = 1536, HC = 64, NCHUNK = HID / HC;
-constexpr int NW = 8, NT = NW * 64;
+// RS = 16-row subtiles per wave: RS = 1 -> 8 waves x 16 rows (two waves per SIMD, every MFMA needs its own weight-fragment read);
+// RS = 2 -> 4 waves x 32 rows, ONE wave per SIMD with the whole 512-entry register file (O: 192 accumulators, A: 96 registers):
+// a weight fragment feeds two MFMAs, so the LDS read port carries half the load. Measured (VDA_MLP_RS=2): 329 us for the clip against
+// 224 us for RS = 1 - one wave per SIMD has nobody to hide its LDS round trips and GELU behind. RS = 1 is what the option runs.
 constexpr int TILE_BYTES = 48 * 1024;                 // W1 chunk [64 x 384] = 6 K tiles of [64][128 B]; W2 chunk [384][128 B]
 constexpr int C_BYTES = 2 * HID * 4;                  // c1 | c2
 constexpr int SMEM = 3 * TILE_BYTES + C_BYTES;
 constexpr int KSTEPS = D / 32;                        // 12 k-steps of GEMM 1
 constexpr int NJ1 = HC / 16;                          // 4 column subtiles of S
 constexpr int NJ2 = D / 16;                           // 24 column subtiles of O
-constexpr int PIECES = TILE_BYTES / 1024 / NW;        // 6 DMA pieces (1 KiB) per wave and tile
 
 template <int KEEP>
 __device__ __forceinline__ void vm_wait_keep() {
@@ -67,7 +69,10 @@ struct Args {
     int M, stats_ld, n_full;
 };
 
-__global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
+template <int RS>
+__global__ void __launch_bounds__(512 / RS) mlp_fused_kernel(const Args p) {
+    constexpr int NW = 8 / RS, NT = NW * 64;
+    constexpr int PIECES = TILE_BYTES / 1024 / NW;        // DMA pieces (1 KiB) per wave and tile: 6 or 12
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,9 +81,11 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
     // rows of this workgroup: 128, or 64 in the tail (waves 4..7 then only issue DMA and keep the barriers)
     const bool full = bid < p.n_full;
     const int row0 = full ? bid * 128 : p.n_full * 128 + (bid - p.n_full) * 64;
-    const int wrow = row0 + wave * 16;
-    const bool active = (full || wave < 4) && wrow < p.M;            // wave-uniform
-    const int m = min(wrow + frow, p.M - 1);                         // this lane's row (clamped: rows past M are computed and dropped)
+    const int wrow = row0 + wave * 16 * RS;
+    const bool active = (full || wave < NW / 2) && wrow < p.M;       // wave-uniform
+    int m[RS];                                                       // this lane's rows (clamped: rows past M are computed and dropped)
+#pragma unroll
+    for (int r = 0; r < RS; ++r) m[r] = min(wrow + r * 16 + frow, p.M - 1);
 
     // ---- DMA: tile t = 2 c + (0: W1 chunk c | 1: W2 chunk c) -> ring buffer t % 3. A piece = 8 rows x 128 B; lane -> (row lrow, chunk).
     const int lrow = lane >> 3;
@@ -88,15 +95,19 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
         char* buf = smem + (t % 3) * TILE_BYTES;
         const int c = t >> 1;
         if ((t & 1) == 0) {
-            // W1 chunk: piece (wave, kt): rows n = 64 c + 8 wave + lrow of K tile kt -> buf + kt * 8 KiB + (8 wave) * 128
-            const h16* src = p.w1 + (size_t)(c * HC + wave * 8 + lrow) * D + src_chk;
+            // W1 chunk: piece (row group g, kt): rows n = 64 c + 8 g + lrow of K tile kt -> buf + kt * 8 KiB + g * 1 KiB; g = wave (+ NW ...)
 #pragma unroll
-            for (int kt = 0; kt < PIECES; ++kt) glds16(src + kt * 64, buf + kt * 8192 + wave * 1024);
+            for (int gi = 0; gi < 8 / NW; ++gi) {
+                const int g = wave + NW * gi;
+                const h16* src = p.w1 + (size_t)(c * HC + g * 8 + lrow) * D + src_chk;
+#pragma unroll
+                for (int kt = 0; kt < 6; ++kt) glds16(src + kt * 64, buf + kt * 8192 + g * 1024);
+            }
         } else {
-            // W2 chunk: piece i of the wave: rows n = 8 (wave + 8 i) + lrow, the chunk's 64 (permuted) hidden columns
+            // W2 chunk: piece i of the wave: rows n = 8 (wave + NW i) + lrow, the chunk's 64 (permuted) hidden columns
             const h16* src = p.w2p + (size_t)(wave * 8 + lrow) * HID + c * HC + src_chk;
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) glds16(src + (size_t)i * 64 * HID, buf + (wave + NW * i) * 1024);
+            for (int i = 0; i < PIECES; ++i) glds16(src + (size_t)i * 8 * NW * HID, buf + (wave + NW * i) * 1024);
         }
     };
     // raw barrier (the LDS-DMA stays in flight across it); the empty asm statements and sched_barriers keep LDS accesses on their
@@ -112,14 +123,16 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
     issue(1);
 
     // ---- the wave's A fragments (k-step s: row frow, k = 32 s + 8 fh .. + 8) and the row's LayerNorm statistics
-    h16x8 a[KSTEPS];
-    {
-        const h16* ap = p.hi_in + (size_t)m * D + fh * 8;
+    h16x8 a[RS][KSTEPS];
+    float nmean[RS], rstd[RS];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) a[s] = *reinterpret_cast<const h16x8*>(ap + s * 32);
+    for (int r = 0; r < RS; ++r) {
+        const h16* ap = p.hi_in + (size_t)m[r] * D + fh * 8;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) a[r][s] = *reinterpret_cast<const h16x8*>(ap + s * 32);
+        const float2 st = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)m[r]);
+        nmean[r] = -st.x, rstd[r] = st.y;
     }
-    const float2 st = *reinterpret_cast<const float2*>(p.stats + 2 * (size_t)m);
-    const float nmean = -st.x, rstd = st.y;
     // c1 | c2 into LDS (fp32, 12 KiB): 3072 floats by 512 threads
     {
         float* cl = reinterpret_cast<float*>(smem + 3 * TILE_BYTES);
@@ -132,13 +145,15 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
     // everything loaded through registers has landed (the two tiles issued above stay in flight: 2 x PIECES younger operations)
     // (hipcc waits vmcnt(0) for the loads above anyway - a VGPR-destination load beside LDS-DMA, cdna_hip_programming.md 4(b) -
     // which costs one exposed L2 round trip per workgroup, once)
-    f32x4 acc[NJ2];
+    f32x4 acc[RS][NJ2];
 #pragma unroll
-    for (int j = 0; j < NJ2; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < RS; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ2; ++j) acc[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* cl = reinterpret_cast<const float*>(smem + 3 * TILE_BYTES);
     const int fsw = (frow >> 1) & 7;                  // ((row >> 1) & 7) of a 16-row subtile's row frow (16 j + frow: 8 j vanishes mod 8)
 
-    h16x8 hf[HC / 32];                                // the chunk's GELU output as the A fragments of GEMM 2
+    h16x8 hf[RS][HC / 32];                            // the chunk's GELU output as the A fragments of GEMM 2
     for (int c = 0; c < NCHUNK; ++c) {
         // ===== phase 2c: S = A . W1c^T, LayerNorm fold + GELU
         vm_wait_keep<PIECES>();                       // tile 2c landed (mine); tile 2c + 1 stays in flight
@@ -146,32 +161,38 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
         issue(2 * c + 2);
         if (active) {
             const char* wb = smem + ((2 * c) % 3) * TILE_BYTES;
-            f32x4 s[NJ1];
+            f32x4 s[RS][NJ1];
 #pragma unroll
-            for (int j = 0; j < NJ1; ++j) s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int j = 0; j < NJ1; ++j) s[r][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const char* kb = wb + (ks >> 1) * 8192 + ((((ks & 1) * 4 + fh) ^ fsw) << 4);
 #pragma unroll
                 for (int j = 0; j < NJ1; ++j) {
                     const h16x8 w = *reinterpret_cast<const h16x8*>(kb + (j * 16 + frow) * 128);
-                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a[ks], s[j], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) s[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, a[r][ks], s[r][j], 0, 0, 0);
                 }
             }
-            // LayerNorm fold (gemm_epilogue.h, VDA_EPI_LN_GELU_F16: rstd * (acc - mean * c1) + c2) and GELU, 16 values per lane
-            float v[NJ1 * 4];
+            // LayerNorm fold (gemm_epilogue.h, VDA_EPI_LN_GELU_F16: rstd * (acc - mean * c1) + c2) and GELU, 16 values per lane and row
 #pragma unroll
-            for (int j = 0; j < NJ1; ++j) {
-                const int n = c * HC + j * 16 + fh * 4;
-                const f32x4 k1 = *reinterpret_cast<const f32x4*>(cl + n), k2 = *reinterpret_cast<const f32x4*>(cl + HID + n);
+            for (int r = 0; r < RS; ++r) {
+                float v[NJ1 * 4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[j * 4 + e] = fmaf(rstd, fmaf(nmean, k1[e], s[j][e]), k2[e]);
+                for (int j = 0; j < NJ1; ++j) {
+                    const int n = c * HC + j * 16 + fh * 4;
+                    const f32x4 k1 = *reinterpret_cast<const f32x4*>(cl + n), k2 = *reinterpret_cast<const f32x4*>(cl + HID + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[j * 4 + e] = fmaf(rstd[r], fmaf(nmean[r], k1[e], s[r][j][e]), k2[e]);
+                }
+                gelu_erf_n(v);
+#pragma unroll
+                for (int q = 0; q < HC / 32; ++q)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) hf[r][q][t] = vda_gemm::to_h16(v[(2 * q + (t >> 2)) * 4 + (t & 3)]);
             }
-            gelu_erf_n(v);
-#pragma unroll
-            for (int q = 0; q < HC / 32; ++q)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) hf[q][t] = vda_gemm::to_h16(v[(2 * q + (t >> 2)) * 4 + (t & 3)]);
         }
         // ===== phase 2c + 1: O += H . W2c^T
         if (c + 1 < NCHUNK) vm_wait_keep<PIECES>();
@@ -186,7 +207,8 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
 #pragma unroll
                 for (int j = 0; j < NJ2; ++j) {
                     const h16x8 w = *reinterpret_cast<const h16x8*>(kb + (j * 16 + frow) * 128);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hf[q], acc[j], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RS; ++r) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w, hf[r][q], acc[r][j], 0, 0, 0);
                 }
             }
         }
@@ -196,47 +218,50 @@ __global__ void __launch_bounds__(NT) mlp_fused_kernel(const Args p) {
 
     // ---- epilogue: x' = (hi + lo) - mean + gamma * (O + b2), re-split into the planes, partial statistics per 64 columns.
     // Lane -> row frow, columns 16 j + 4 fh + e: 8-byte accesses, a row's four lane groups complete 32-byte runs; once per workgroup.
-    const bool ok = wrow + frow < p.M;
-    const size_t rbase = (size_t)m * D + fh * 4;
 #pragma unroll
-    for (int b = 0; b < D / 64; ++b) {
-        float v[16];
+    for (int r = 0; r < RS; ++r) {
+        const bool ok = wrow + r * 16 + frow < p.M;
+        const size_t rbase = (size_t)m[r] * D + fh * 4;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = b * 4 + jj, n = j * 16 + fh * 4;
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + n), gg = *reinterpret_cast<const f32x4*>(p.gamma + n);
-            const h16x4 xh = *reinterpret_cast<const h16x4*>(p.hi + rbase + j * 16), xl = *reinterpret_cast<const h16x4*>(p.lo + rbase + j * 16);
-            h16x4 oh, ol;
+        for (int b = 0; b < D / 64; ++b) {
+            float v[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = fmaf(gg[e], acc[j][e] + bb[e], ((float)xh[e] + (float)xl[e]) + nmean);
-                h16 hh, ll;
-                vda_gemm::split_h16(x, hh, ll);
-                oh[e] = hh;
-                ol[e] = ll;
-                v[jj * 4 + e] = x;
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = b * 4 + jj, n = j * 16 + fh * 4;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b2 + n), gg = *reinterpret_cast<const f32x4*>(p.gamma + n);
+                const h16x4 xh = *reinterpret_cast<const h16x4*>(p.hi + rbase + j * 16), xl = *reinterpret_cast<const h16x4*>(p.lo + rbase + j * 16);
+                h16x4 oh, ol;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = fmaf(gg[e], acc[r][j][e] + bb[e], ((float)xh[e] + (float)xl[e]) + nmean[r]);
+                    h16 hh, ll;
+                    vda_gemm::split_h16(x, hh, ll);
+                    oh[e] = hh;
+                    ol[e] = ll;
+                    v[jj * 4 + e] = x;
+                }
+                if (ok) {
+                    *reinterpret_cast<h16x4*>(p.hi + rbase + j * 16) = oh;
+                    *reinterpret_cast<h16x4*>(p.lo + rbase + j * 16) = ol;
+                }
             }
-            if (ok) {
-                *reinterpret_cast<h16x4*>(p.hi + rbase + j * 16) = oh;
-                *reinterpret_cast<h16x4*>(p.lo + rbase + j * 16) = ol;
+            // (sum, centred sum of squares) of the row's 64 columns: 16 in this lane, the rest in lanes frow + 16, + 32, + 48
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sum += v[i];
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            const float mean = sum * (1.f / 64.f);
+            float sq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float d = v[i] - mean;
+                sq = fmaf(d, d, sq);
             }
+            sq += __shfl_xor(sq, 16, 64);
+            sq += __shfl_xor(sq, 32, 64);
+            if (ok && fh == 0) *reinterpret_cast<float2*>(p.part + ((size_t)b * p.stats_ld + (wrow + r * 16 + frow)) * 2) = float2{sum, sq};
         }
-        // (sum, centred sum of squares) of the row's 64 columns: 16 in this lane, the rest in lanes frow + 16, + 32, + 48
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sum += v[i];
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.f / 64.f);
-        float sq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float d = v[i] - mean;
-            sq = fmaf(d, d, sq);
-        }
-        sq += __shfl_xor(sq, 16, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        if (ok && fh == 0) *reinterpret_cast<float2*>(p.part + ((size_t)b * p.stats_ld + (wrow + frow)) * 2) = float2{sum, sq};
     }
 }
 
@@ -269,8 +294,10 @@ extern "C" int vda_mlp_fused_f16(const void* hi_in, const float* stats, const vo
     VDA_REQUIRE((((uintptr_t)hi_in | (uintptr_t)w1 | (uintptr_t)w2p | (uintptr_t)hi | (uintptr_t)lo | (uintptr_t)c1 | (uintptr_t)c2 | (uintptr_t)b2 | (uintptr_t)gamma) & 15) == 0 &&
                     (((uintptr_t)stats | (uintptr_t)part) & 7) == 0,
                 "vda_mlp_fused_f16: operands must be 16-byte aligned (statistics 8)");
-    static VdaKernelDeviceState dev_state;
-    const int ncu = vda_prepare_kernel(reinterpret_cast<const void*>(&mlp_fused_kernel), SMEM, dev_state);
+    static const int rs = getenv("VDA_MLP_RS") ? atoi(getenv("VDA_MLP_RS")) : 1;       // A/B: 1 = 8 waves x 16 rows (default), 2 = 4 waves x 32 rows
+    static VdaKernelDeviceState dev_state1, dev_state2;
+    const int ncu = rs == 1 ? vda_prepare_kernel(reinterpret_cast<const void*>(&mlp_fused_kernel<1>), SMEM, dev_state1)
+                            : vda_prepare_kernel(reinterpret_cast<const void*>(&mlp_fused_kernel<2>), SMEM, dev_state2);
     if (ncu < 0) return 2;
     // full 128-row workgroups for at most one round of the chip; what is left goes out in 64-row workgroups
     Args a;
@@ -279,7 +306,8 @@ extern "C" int vda_mlp_fused_f16(const void* hi_in, const float* stats, const vo
     a.n_full = M / 128 < ncu ? M / 128 : ncu;
     const int tail = M - a.n_full * 128;
     const int grid = a.n_full + (tail + 63) / 64;
-    hipLaunchKernelGGL(mlp_fused_kernel, dim3(grid), dim3(NT), SMEM, (hipStream_t)stream, a);
+    if (rs == 1) hipLaunchKernelGGL(mlp_fused_kernel<1>, dim3(grid), dim3(512), SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(mlp_fused_kernel<2>, dim3(grid), dim3(256), SMEM, (hipStream_t)stream, a);
     VDA_LAUNCH_CHECK();
     return 0;
 }
