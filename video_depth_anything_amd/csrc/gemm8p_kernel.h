@@ -90,7 +90,11 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // per XCD; any other shape keeps the default walk.
     const int dbg2 = __builtin_amdgcn_readfirstlane((p.relu_in >> 16) & 0xff);
     const int cgroups = nbn >> 2;
-    const bool blocked = (dbg2 & 2) && (nbn & 3) == 0 && cgroups >= 1 && cgroups <= 8 && (8 % cgroups) == 0 && per_xcd == 32 && !DYN;
+    // DEFAULT for nbn = 8, 16, 32 (fc1: the dominant kernel fetched 8.5 x its algorithmic bytes without it; -3 % on that launch alone,
+    // neutral on the power-capped forward); nbn = 4 (proj / fc2: W is 2 / 8 MB for ALL columns, the default walk already shares it) only
+    // when debug bit 1 asks for it (measured +1 % slower there); debug bit 4 switches it off everywhere (A/B).
+    const bool blocked = (cgroups == 2 || cgroups == 4 || cgroups == 8 || ((dbg2 & 2) && cgroups == 1)) && (nbn & 3) == 0 && per_xcd == 32 && !DYN &&
+                         !(dbg2 & 16) && full_rounds > 0;
     auto tile_of = [&](int round) {
         if (blocked) {
             const int x = bid & 7, slot = bid >> 3, xpg = 8 / cgroups;
