@@ -82,23 +82,28 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // the plain mapping stays). A workgroup without a tile in that round has one tile time of slack: see the stagger below.
     const int full_rounds = ntiles / nwg, rem = ntiles - full_rounds * nwg;
     const bool deal_last = rem > 0 && full_rounds > 0 && per_xcd % nbn == 0;
-    // DIAGNOSTIC switches (vda_gemm_set_debug, never set by the model): bit 0 = clock stamps (below), bit 1 = L2-BLOCKED tile order.
-    // Blocked order: an XCD keeps ONE group of four column panels for the whole launch (its W slice, 4 x 256 x K x 2 B = 2 MB at
-    // K = 1024, stays in its 4 MB L2) and walks down the row panels, eight per round, interleaved with the other XCDs of its column
-    // group - instead of 32 consecutive tiles per round (N fastest), which at nbn = 16 re-fetches all 8 MB of W past L2 every
-    // round (fc1: 832 MB fetched per launch against 98 MB algorithmic, profiles/r03). Needs nbn = 4, 8, 16 or 32 and 32 workgroups
-    // per XCD; any other shape keeps the default walk.
+    // L2-BLOCKED tile order: an XCD keeps ONE group of CG column panels for the whole launch (its W slice - 4 x 256 x K x 2 B = 2 MB at
+    // K = 1024 - stays in its 4 MB L2) and walks down the row panels, interleaved with the other XCDs of its column group, instead of
+    // 32 consecutive tiles per round (N fastest), which at nbn = 16 re-fetches all 8 MB of W past L2 every round (fc1: 832 MB fetched
+    // per launch against 98 MB algorithmic, profiles/r03; 546 MB with it, profiles/r04). Needs 32 workgroups per XCD and at least one
+    // full round; any other launch keeps the default walk. vda_gemm_set_debug: bit 0 = clock stamps (below), bit 1 = blocked also for
+    // nbn = 4, bit 4 = never blocked.
     const int dbg2 = __builtin_amdgcn_readfirstlane((p.relu_in >> 16) & 0xff);
-    const int cgroups = nbn >> 2;
-    // DEFAULT for nbn = 8, 16, 32 (fc1: the dominant kernel fetched 8.5 x its algorithmic bytes without it; -3 % on that launch alone,
-    // neutral on the power-capped forward); nbn = 4 (proj / fc2: W is 2 / 8 MB for ALL columns, the default walk already shares it) only
-    // when debug bit 1 asks for it (measured +1 % slower there); debug bit 4 switches it off everywhere (A/B).
-    const bool blocked = (cgroups == 2 || cgroups == 4 || cgroups == 8 || ((dbg2 & 2) && cgroups == 1)) && (nbn & 3) == 0 && per_xcd == 32 && !DYN &&
-                         !(dbg2 & 16) && full_rounds > 0;
+    // Column group width CG (panels) and the number of groups G = nbn / CG (2, 4 or 8: 8 / G XCDs share a group and interleave its
+    // row panels): nbn = 8, 16, 32 -> CG 4; on request (debug bit 1) also nbn = 12 (qkv), 24 -> CG 6 and nbn = 4 -> one group: qkv
+    // measured 275.0 against 272.7 us with it on one box - no gain; the sign of the fc1 gain itself flips between boxes (-1.5 % / +0.7 %).
+    // DEFAULT for those widths (fc1: the dominant kernel fetched 8.5 x its algorithmic bytes without it; -1.5 .. -3 % on that launch
+    // alone, +0.3 % on the power-capped forward); nbn = 4 (proj / fc2: the default walk already shares all of W) only when debug bit 1
+    // asks for it (measured +1 % slower there); debug bit 4 switches it off everywhere (A/B).
+    const int cgw = (nbn % 4 == 0 && (nbn == 8 || nbn == 16 || nbn == 32 || (nbn == 4 && (dbg2 & 2)))) ? 4 : (((nbn == 12 || nbn == 24) && (dbg2 & 2)) ? 6 : 0);
+    const int cgroups = cgw ? nbn / cgw : 1;
+    const bool blocked = cgw != 0 && per_xcd == 32 && !DYN && !(dbg2 & 16) && full_rounds > 0;
     auto tile_of = [&](int round) {
         if (blocked) {
+            // the group's tiles in row-major order (CG wide), dealt 32 at a time to its XCDs: XCD i of the group takes chunk r * xpg + i
             const int x = bid & 7, slot = bid >> 3, xpg = 8 / cgroups;
-            const int rp = (round * xpg + x / cgroups) * 8 + (slot >> 2), cp = (x % cgroups) * 4 + (slot & 3);
+            const int idx = ((round * xpg + x / cgroups) << 5) + slot;
+            const int rp = idx / cgw, cp = (x % cgroups) * cgw + (idx - rp * cgw);
             return rp < nbm ? rp * nbn + cp : ntiles;
         }
         if (deal_last && round == full_rounds) {
