@@ -102,9 +102,16 @@ inline unsigned grid_for(size_t items) {
 
 // A forward whose split residual stream left fp16's range has no valid result: its depth is overwritten with NaN so that the
 // failure is visible in the data as well as in the status (a clamped ReLU would otherwise turn NaN activations into zeros).
-__global__ void __launch_bounds__(256) poison_on_overflow_kernel(const int* __restrict__ flag, float* __restrict__ depth, long long n) {
+// ... and the report goes to a STICKY word in pinned host memory (written only when set: a later, clean forward cannot erase it however
+// far the host runs ahead of the device).
+__global__ void __launch_bounds__(256) poison_on_overflow_kernel(const int* __restrict__ flag, float* __restrict__ depth, long long n,
+                                                                 volatile int* __restrict__ host_report) {
     if (*flag == 0) return;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) depth[i] = __builtin_nanf("");
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *host_report = 1;
+        __threadfence_system();
+    }
 }
 
 struct Raw {
@@ -172,11 +179,9 @@ struct vda_model {
     std::map<hipStream_t, Side> sides;        // one side stream + event pair per caller stream (two forwards may be in flight on two)
     int mlp_fused = 0;                        // vda_set_option("mlp_fused"): fc1 + GELU + fc2 + residual in one kernel where built (D = 384; needs ln_fold).
                                               // OFF: measured slower than the two GEMM launches (ViT-S clip 8.69 -> 9.00 ms, mlp_fused.hip's header)
-    // Split-stream overflow reports (ln_fold): each forward's device flag is copied, at its end and on its stream, into the next
-    // word of this pinned ring; vda_forward_status / the next vda_forward read the words whose forwards have completed.
-    static constexpr int OVF_RING = 16;
-    volatile int32_t* ovf_host = nullptr;     // hipHostMalloc'ed [OVF_RING]
-    unsigned long long forwards = 0;          // forwards enqueued so far (ring position)
+    // Split-stream overflow report (ln_fold): one sticky word in pinned host memory, set by the device at the end of a forward whose
+    // flag was raised; vda_forward_status / the next vda_forward read (and clear) it.
+    volatile int32_t* ovf_host = nullptr;     // hipHostMalloc'ed, device-visible
 };
 
 namespace {
@@ -981,10 +986,8 @@ struct Run {
         }
         // video_depth.py:162-163: bilinear to (H,W) is the identity here (H == 14*ph) and the final ReLU is idempotent.
         if (fold && !dry) {
-            hipLaunchKernelGGL(poison_on_overflow_kernel, dim3(256), dim3(256), 0, s, (const int*)ovf, depth, (long long)BT * H * Wd);
+            hipLaunchKernelGGL(poison_on_overflow_kernel, dim3(256), dim3(256), 0, s, (const int*)ovf, depth, (long long)BT * H * Wd, (volatile int*)h->ovf_host);
             VDA_LAUNCH_CHECK();
-            VDA_HIP(hipMemcpyAsync((void*)(h->ovf_host + h->forwards % vda_model::OVF_RING), ovf, 4, hipMemcpyDeviceToHost, s));
-            ++h->forwards;
         }
         return 0;
     }
@@ -1052,13 +1055,13 @@ extern "C" int vda_create(const vda_config* cfg, vda_model** out) {
         return 2;
     }
     void* ring = nullptr;
-    if (hipHostMalloc(&ring, sizeof(int32_t) * vda_model::OVF_RING, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&ring, 64, hipHostMallocDefault) != hipSuccess) {
         for (void* p : h->owned) (void)hipFree(p);
         delete h;
         vda_set_error("vda_create: pinned host allocation failed");
         return 2;
     }
-    memset(ring, 0, sizeof(int32_t) * vda_model::OVF_RING);
+    memset(ring, 0, 64);
     h->ovf_host = (volatile int32_t*)ring;
     *out = h;
     return 0;
@@ -1184,14 +1187,8 @@ extern "C" int vda_set_workspace(vda_model* h, void* ptr, int64_t bytes) {
 // Overflow reports that have ARRIVED (their forward's stream work has completed): collected and cleared. A word still in flight
 // reads 0 and is seen by a later call. Status 4 + a message naming the way out.
 static int collect_overflow(vda_model* h, const char* who) {
-    bool any = false;
-    for (int i = 0; i < vda_model::OVF_RING; ++i) {
-        if (h->ovf_host[i] != 0) {
-            any = true;
-            h->ovf_host[i] = 0;
-        }
-    }
-    if (!any) return 0;
+    if (h->ovf_host[0] == 0) return 0;
+    h->ovf_host[0] = 0;
     vda_set_error("%s: in a forward since the last check the split residual stream left fp16's range (a token further than 65504 from its own "
                   "mean): that forward's depth was overwritten with NaN. vda_set_option(h, \"ln_fold\", 0) keeps the stream in fp32 (the reference's "
                   "form, no such limit); fp32=True avoids it as well", who);
