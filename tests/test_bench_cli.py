@@ -18,9 +18,10 @@ def _run(args, env=None, timeout=300):
 
 
 def test_self_launch_starts_the_launcher_as_a_child_and_relays_its_exit_code(tmp_path):
-    """A stand-in launcher module (PYTHONPATH shadows nothing: the child command is `python -m torch.distributed.run`, so the
-    stand-in is injected as sitecustomize-free env marker instead): the ranks started here have no GPU and must fail - what is
-    checked is that the PARENT got as far as starting them with the right command and passed their failure on."""
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent must announce and start the launcher command
+    (same arguments, 127.0.0.1 rendezvous) as a child process and pass its exit code on. In this container the ranks have no GPU and
+    must fail - what is checked is that the PARENT got as far as starting them and relayed the failure instead of dying in argument
+    handling; on a GPU box the same call has to produce the one JSON line."""
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--encoder", "vits", "--no-cpu-baseline"], env={"VDA_BENCH_BACKEND": "gloo"})
     assert "[bench] --gpus 2 without a launcher: starting -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1" in r.stderr, r.stderr[-2000:]
     import torch
