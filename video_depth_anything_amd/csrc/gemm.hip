@@ -475,6 +475,10 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
         if (stagger == 2) a8.relu_in |= 32 << 8;             // A/B: panel-aligned phases
         if (eight && g_gemm_variant > 0) a8.relu_in = (a.relu_in & 0xff) | (((g_gemm_variant >> 4) & 0xff) << 8);   // A/B switches
         a8.relu_in |= g_gemm_debug << 16;                      // vda_gemm_set_debug (0 unless a diagnostic tool set it)
+        // Non-temporal output stores (8-phase kernel, fp16 row stores) for outputs that no cache will hand to the next kernel:
+        // VDA_GEMM_NT_MB (default 192; 0 = never) megabytes and up. ViT-L: qkv, hid, the GEGLU hidden, the 148^2 conv maps; ViT-S: none.
+        static const long long nt_mb = getenv("VDA_GEMM_NT_MB") ? atoll(getenv("VDA_GEMM_NT_MB")) : 192;
+        if (nt_mb > 0 && (long long)a.M * a.N * 2 >= nt_mb * 1000000ll) a8.relu_in |= 1 << 24;
         const int sched8 = (eight && g_gemm_variant > 0) ? ((g_gemm_variant >> 5) & 3) : 0;   // A/B: variant 5 + 32 * sched
         // 192-row tiles when they quantise better on this device: rounds of 256-row tiles against 3/4-size rounds of 192-row tiles
         // (ViT-S proj / fc2: 3 against 2.25; variant 8 forces them). Only the one-barrier 256 x 128 family has the shape.

@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
     // (qkv: +11 us per launch with per-group global loads). The split-residual epilogue uses the same slice the other way:
     // its partial row statistics are collected there and leave as two 512-byte stores per wave tile.
     constexpr bool LN_EPI = vda_gemm::is_ln_epi<EPI>;
+    constexpr bool RT_F32OUT = vda_gemm::RowTraits<EPI>::f32_out || EPI == VDA_EPI_SCALE_RES_SPLIT;      // epilogues that do not go through store8h
     constexpr bool STAT_LDS = LN_EPI || EPI == VDA_EPI_SCALE_RES_SPLIT;
     static_assert(!STAT_LDS || (WTM <= 128 && W_BYTES >= NW * 1024), "statistics slice: 1 KiB per wave in W slot 1");
     char* const sst = smem + W_BASE + W_BYTES + wave * 1024;
@@ -545,6 +546,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
         // residual reads and the output stores become contiguous 16-byte accesses covering full 128-byte lines.
         const int bm0 = m0 + wm * WTM, bn0 = n0 + wn * WTN;
         const bool interior = bm0 + WTM <= p.M && bn0 + WTN <= p.N;       // wave-uniform
+        const bool nt_out = !RT_F32OUT && __builtin_amdgcn_readfirstlane((p.relu_in >> 24) & 1) != 0;      // set by vda_gemm_f16 for outputs past the caches
         if constexpr (LN_EPI) {
             *reinterpret_cast<float2*>(sst + lane * 8) = nstat[0];
             if constexpr (WTM > 64) *reinterpret_cast<float2*>(sst + (64 + lane) * 8) = nstat[1];
@@ -598,8 +600,9 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                 // phase 2 reads the transposed accumulators back, finishes and stores.
                 // Row-dependent loads (residuals, pos-embed) run ONE ROW GROUP AHEAD of the stores: vmcnt retires in order and
                 // counts stores, so a load issued after a group's stores cannot complete before them - issued before, it can.
-                auto row_groups = [&](auto guard) {
+                auto row_groups = [&](auto guard, auto nt_tag) {
                     constexpr bool GUARD = decltype(guard)::value;
+                    constexpr bool NTS = decltype(nt_tag)::value;              // non-temporal output stores (gemm_epilogue.h, store8h)
                     constexpr int NG = RR / RG;                                  // row groups per 32-row block
                     auto load_group = [&](int blk, int r0, vda_gemm::RowAux (&ax)[RG]) {
                         if constexpr (LN_EPI) {
@@ -645,7 +648,7 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                                         gt[4 + e] = gb[e];
                                     }
                                 }
-                                if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD, false>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
+                                if (!geglu_idle) vda_gemm::finish_row8<EPI, GUARD, false, NTS>(p, bm0 + i * 32 + row, en, v, gt, cc, aux[g & 1][q]);
                                 if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT)        // the row's 8 lanes hold the same pair (rows past M: never stored)
                                     *reinterpret_cast<float2*>(sst + (i * 32 + row) * 8) = float2{aux[g & 1][q].o0, aux[g & 1][q].o1};
                             }
@@ -653,8 +656,14 @@ __global__ void __launch_bounds__(NT) gemm8p_kernel(const vda_gemm_args p) {
                     }
                 };
                 // interior wave tiles (all but the matrix's last row / column of tiles) take the branch-free form
-                if (interior) row_groups(std::false_type{});
-                else row_groups(std::true_type{});
+                // (three copies of the block: interior with ordinary stores, interior with non-temporal ones - a wave-uniform choice made
+                // once per launch by the dispatcher from the output's size - and the guarded form for the matrix's edge tiles)
+                if (interior) {
+                    if (nt_out) row_groups(std::false_type{}, std::true_type{});
+                    else row_groups(std::false_type{}, std::false_type{});
+                } else {
+                    row_groups(std::true_type{}, std::false_type{});
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads of this block done before the next block's writes
                 // Epilogues with row-dependent loads (residual, pos-embed) prefetch after their LAST block instead: with an LDS-DMA
                 // in flight hipcc waits vmcnt(0) - every store included - at each of those loads (dbg bit 2 switches this off)

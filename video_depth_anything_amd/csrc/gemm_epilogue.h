@@ -157,11 +157,19 @@ __device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
     }
 }
 
+// NT: a non-temporal store (`global_store_dwordx4 ... nt`). For outputs far larger than the caches can hand to the next kernel (ViT-L's
+// hid 359 MB, qkv 270 MB, the 148 x 148 conv maps 359 MB) it keeps the streamed lines from displacing the A / W panels in L2 and
+// leaves fewer dirty lines behind at the kernel boundary: fc1 -2.0 %, qkv -2.8 %, the ViT-L forward 50.21 -> 49.67 ms (+1.1 %) in
+// one process with two builds. ONLY for these full-line 16-byte row stores and only for big outputs: on ViT-S (hid 135 MB: the Infinity
+// Cache hands it to fc2) it costs 0.6 %, and on the 8-byte-per-lane stores of the attention / conv kernels - which rely on L2 to merge
+// them into lines - it costs 3.5 % of the ViT-L forward and 14 % of ViT-S (profiles/r04/nt_stores_ab.txt).
+template <bool NT = false>
 __device__ __forceinline__ void store8h(h16* p, const float (&v)[8]) {
     h16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = to_h16(v[i]);
-    *reinterpret_cast<h16x8*>(p) = o;
+    if constexpr (NT) __builtin_nontemporal_store(o, reinterpret_cast<h16x8*>(p));
+    else *reinterpret_cast<h16x8*>(p) = o;
 }
 
 // Per-lane column constants (bias / LayerScale for the lane's NC columns), loaded once per tile.
@@ -264,7 +272,7 @@ __device__ __forceinline__ void load_row_aux(const vda_gemm_args& p, int m, int 
     }
 }
 
-template <int EPI, bool GUARD = true, bool BIAS = true>
+template <int EPI, bool GUARD = true, bool BIAS = true, bool NT = false>
 __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n, float (&v)[8], float (&g)[8],
                                             const ColConst<8>& c, const RowAux& x) {
     if (GUARD && (m >= p.M || n >= p.N)) return;
@@ -277,7 +285,7 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaf(x.s1, fmaf(-x.s0, c.gamma[i], v[i]), c.bias[i]);
         if constexpr (EPI == VDA_EPI_LN_GELU_F16) gelu_erf_n(v);
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_SPLIT) {
         // the row's 64 columns of this wave tile sit in 8 consecutive lanes (all inside the matrix together: N % 64 == 0)
         h16x8 oh, ol;
@@ -306,14 +314,14 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         x.o0 = sum;
         x.o1 = sum8(sq);
     } else if constexpr (EPI == VDA_EPI_BIAS_F16) {
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_GELU_F16) {
         gelu_erf_n(v);
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_BIAS_RELU_F16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_RES_F16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += (float)x.h0[i];
@@ -321,14 +329,14 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += (float)x.h1[i];
         }
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_SCALE_RES_F32_H) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[i] = fmaf(c.gamma[i], v[i], x.f0[i]);                 // explicit fma: identical rounding in every instantiation
             v[4 + i] = fmaf(c.gamma[4 + i], v[4 + i], x.f1[i]);
         }
-        store8h((h16*)p.out + (size_t)m * p.ldc + n, v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + n, v);
     } else if constexpr (EPI == VDA_EPI_GEGLU_F16) {
         // n is a VALUE column group (n % 32 < 16); g holds columns n+16.. (the gates)
         if constexpr (BIAS) {
@@ -338,7 +346,7 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         gelu_erf_n(g);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= g[i];
-        store8h((h16*)p.out + (size_t)m * p.ldc + ((n >> 5) * 16 + (n & 15)), v);
+        store8h<NT>((h16*)p.out + (size_t)m * p.ldc + ((n >> 5) * 16 + (n & 15)), v);
     } else if constexpr (EPI == VDA_EPI_CONVT_F16) {
         const int k = p.tK, Co = p.tCout;
         const int tap = n / Co, co = n - tap * Co;
@@ -347,7 +355,7 @@ __device__ __forceinline__ void finish_row8(const vda_gemm_args& p, int m, int n
         const int b = m / hw, rem = m - b * hw;
         const int y = rem / p.tW, xx = rem - y * p.tW;
         const size_t orow = ((size_t)b * p.tH * k + (size_t)y * k + ky) * ((size_t)p.tW * k) + (size_t)xx * k + kx;
-        store8h((h16*)p.out + orow * p.ldc + co, v);
+        store8h<NT>((h16*)p.out + orow * p.ldc + co, v);
     }
 }
 
