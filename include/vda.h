@@ -271,6 +271,9 @@ int vda_head_out_f32_f32(const float* in, const float* w, float bias, float* out
  * -> fp32 [B,H,W]. w2: fp16 [32, 9*C] with K ordered (ky,kx,ci); C a multiple of 32; zero_page: >= 256 B of zeros. */
 int vda_depth_tail_f16(const void* in, const void* w2, const float* b2, const float* w3, float b3, float* out,
                        const void* zero_page, int B, int h, int w, int H, int W, int C, vda_stream_t stream);
+/* A/B switch of the resizing form: 0 (default) = the persistent kernel with the weights resident in LDS (C <= 128), 1 = the round-1
+ * kernel (one 8 x 32 tile per workgroup). Same arithmetic, bit-identical results. */
+int vda_depth_tail_set_variant(int v);
 
 /* output_conv1 applied to the 2x-upsampled output of refinenet1 (dpt.py:117 over util/blocks.py:156-160's
  * F.interpolate(scale_factor=2, mode="bilinear", align_corners=True)) in one pass: NHWC fp16 in [B,h,w,C] ->

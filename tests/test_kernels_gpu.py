@@ -736,6 +736,28 @@ def test_depth_tail(ops, Cc, h, w_, H, W_):
     close(out, ref, rtol=2e-3, atol=3e-3, what="depth tail")
 
 
+@pytest.mark.parametrize("Cc,B,h,w_,H,W_", [(32, 2, 12, 12, 21, 21), (64, 3, 40, 50, 70, 88), (128, 2, 17, 19, 29, 45), (128, 8, 92, 92, 161, 161),
+                                            (128, 1, 296, 296, 518, 518)])
+def test_depth_tail_persistent_equals_v1(ops, Cc, B, h, w_, H, W_):
+    """The persistent resizing tail (weights resident in LDS, two patch buffers; more tiles than workgroups in the last two cases)
+    against the round-1 kernel: same arithmetic per output pixel, so bit-identical."""
+    from video_depth_anything_amd import _lib
+    x = dev(rnd(B, h, w_, Cc, seed=74).to(F16))
+    w2, b2 = dev(ops.pack_conv3x3(rnd(32, Cc, 3, 3, seed=75, scale=(9 * Cc) ** -0.5))), dev(rnd(32, seed=76))
+    w3, b3 = dev(rnd(32, seed=77, scale=0.3)), 0.4
+    outs = []
+    try:
+        for v in (1, 0):
+            _lib.lib.vda_depth_tail_set_variant(v)
+            out = torch.full((B, H, W_), float("nan"), dtype=F32, device="cuda")
+            ops.depth_tail(x, w2, b2, w3, b3, out, B, h, w_, H, W_, Cc)
+            outs.append(out)
+    finally:
+        _lib.lib.vda_depth_tail_set_variant(0)
+    assert torch.isfinite(outs[1]).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gather_normalize_equals_normalize_of_gathered(ops):
     rng = np.random.default_rng(6)
     video = rng.integers(0, 256, (9, 14, 28, 3), dtype=np.uint8)
