@@ -287,6 +287,7 @@ inline int src_extent(float scale, int tile, int halo_lo, int out_n, int in_n) {
     return ext;
 }
 
+template <int DBG>
 __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restrict__ in, const h16* __restrict__ w2, const float* __restrict__ b2,
                                                             const float* __restrict__ w3, float b3, float* __restrict__ out, int h, int w, int H,
                                                             int W, int C, int tiles_x, int tiles_y, int ntiles, float ys, float xs, int SH, int SW) {
@@ -391,10 +392,18 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
             }
         };
         auto interp = [&](const char* sb, char* pb) __attribute__((always_inline)) {
+            if constexpr (DBG == 1) return;                    // TIMING EXPERIMENT 1: no interpolation (DMA + barriers only)
 #pragma unroll
             for (int k = 0; k < NKF; ++k) {
                 const h16x8 a00 = *reinterpret_cast<const h16x8*>(sb + (ia[k] & 0xffffu)), a01 = *reinterpret_cast<const h16x8*>(sb + (ia[k] >> 16));
                 const h16x8 a10 = *reinterpret_cast<const h16x8*>(sb + (ib[k] & 0xffffu)), a11 = *reinterpret_cast<const h16x8*>(sb + (ib[k] >> 16));
+                if constexpr (DBG == 3) {                      // TIMING EXPERIMENT 3: the LDS traffic of the interpolation without its arithmetic
+                    uint4 x = *reinterpret_cast<const uint4*>(&a00);
+                    const uint4 y = *reinterpret_cast<const uint4*>(&a01), z = *reinterpret_cast<const uint4*>(&a10), t = *reinterpret_cast<const uint4*>(&a11);
+                    x.x ^= y.x ^ z.x ^ t.x; x.y ^= y.y ^ z.y ^ t.y; x.z ^= y.z ^ z.z ^ t.z; x.w ^= y.w ^ z.w ^ t.w;
+                    *reinterpret_cast<uint4*>(pb + woff[k]) = x;
+                    continue;
+                }
                 *reinterpret_cast<h16x8*>(pb + woff[k]) = bilinear8(a00, a01, a10, a11, bw[k]);
             }
         };
@@ -478,6 +487,10 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
     };
     int u = 0;
     auto unit = [&]() __attribute__((always_inline)) {
+        if constexpr (DBG == 2) {                              // TIMING EXPERIMENT 2: no MFMA phase (the fill waves' own pace)
+            ++u;
+            return;
+        }
         const char* const pc = patch + (u & 1) * PATCH_BYTES2;
         const char* const wc = wring + (u & 1) * W_PASS_BYTES;
         Frag f[2];
@@ -551,15 +564,17 @@ extern "C" int vda_depth_tail_f16(const void* in, const void* w2, const float* b
     // v2: persistent, specialised waves, source region staged in LDS (tools/tail_bench.py; variant 1 = v1 for A/B). Needs the region
     // under a 18 x 34 patch to fit 256 pixels - any upsampling by >= ~1.3 does (1.75 everywhere in the product)
     const int SH = v2::src_extent(ys, v2::TH2, -1, H, h), SW = v2::src_extent(xs, v2::TW2, -1, W, w);
-    if ((h != H || w != W) && SH * SW <= v2::SRC_ROWS && g_tail_variant != 1) {
+    if ((h != H || w != W) && SH * SW <= v2::SRC_ROWS && (g_tail_variant & 15) != 1) {
         const int tx2 = (W + v2::TW2 - 1) / v2::TW2, ty2 = (H + v2::TH2 - 1) / v2::TH2;
         const long long nt2 = (long long)tx2 * ty2 * B;
         VDA_REQUIRE(nt2 < (1ll << 30), "vda_depth_tail: too many tiles");
-        static VdaKernelDeviceState dev_state;
-        const int ncu = vda_prepare_kernel(reinterpret_cast<const void*>(&v2::depth_tail_up_kernel), v2::SMEM2, dev_state);
+        static VdaKernelDeviceState dev_state[4];
+        const int dbg = (g_tail_variant >> 4) & 3;
+        auto* const fn = dbg == 1 ? &v2::depth_tail_up_kernel<1> : dbg == 2 ? &v2::depth_tail_up_kernel<2> : dbg == 3 ? &v2::depth_tail_up_kernel<3> : &v2::depth_tail_up_kernel<0>;
+        const int ncu = vda_prepare_kernel(reinterpret_cast<const void*>(fn), v2::SMEM2, dev_state[dbg]);
         if (ncu < 0) return 2;
         const int grid2 = (int)(nt2 < ncu ? (nt2 + 7) / 8 * 8 : ncu);
-        hipLaunchKernelGGL(v2::depth_tail_up_kernel, dim3(grid2), dim3(v2::NT2), v2::SMEM2, s, (const h16*)in, (const h16*)w2, b2, w3, b3, out, h, w, H, W, C,
+        hipLaunchKernelGGL(fn, dim3(grid2), dim3(v2::NT2), v2::SMEM2, s, (const h16*)in, (const h16*)w2, b2, w3, b3, out, h, w, H, W, C,
                            tx2, ty2, (int)nt2, ys, xs, SH, SW);
         VDA_LAUNCH_CHECK();
         return 0;
