@@ -282,6 +282,8 @@ int vda_depth_tail_set_variant(int v);
  * The interpolated pixels are rounded to fp16 once, exactly as vda_bilinear_nhwc_f16 would have stored them. */
 int vda_conv3x3_up2_f16(const void* in, const void* w, const float* bias, void* out, int B, int h, int wd, int C, int N, int ldc,
                         vda_stream_t stream);
+/* Timing experiments of the fused kernel at N > 64 (results invalid): 1 = no interpolation, 2 = no MFMA groups; 0 = the kernel. */
+int vda_conv3x3_up2_set_variant(int v);
 
 /* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
  * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */

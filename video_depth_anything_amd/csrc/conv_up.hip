@@ -43,8 +43,16 @@ constexpr int NI = (NITEM + NT - 1) / NT;      // 3 per thread
 
 __device__ __forceinline__ int swz(int r) { return (r >> 3) & 1; }
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ swz(row)) << 4); }
+// [r4] the PATCH image is swizzled by the pixel's COLUMN in the patch, (col >> 3) & 1, instead of its row index: conflict-free for the
+// same reason (the lanes of a ds_read_b128 group that share a row-mod-8 are 8 or 24 columns apart), and a reading lane's swizzle then
+// depends on pixel + kx only: the patch fragment addresses of a k-step are 3 lane constants + immediates, the weight fragment addresses
+// one (rows R = 32 (...) + cout: (R >> 3) & 1 = (cout >> 3) & 1), instead of ~70 VALU instructions per k-step and wave.
+__device__ __forceinline__ int patch_off(int q, int chunk) {
+    const int col = q % PW;
+    return q * ROWB + ((chunk ^ ((col >> 3) & 1)) << 4);
+}
 
-template <int CB>
+template <int CB, int DBG = 0>
 __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__ in, const h16* __restrict__ wt, const float* __restrict__ bias,
                                                          h16* __restrict__ out, int h, int w, int C, int N, int ldc, int tiles_x,
                                                          int tiles_y, int ntiles) {
@@ -65,15 +73,22 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     const int ty = tyb % tiles_y, b = tyb / tiles_y;
     const int x0 = tx * TW, y0 = ty * TH;
     const int px = lane & 31, hh = lane >> 5;
+    const bool wide = (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)out & 15) == 0;     // uniform
 
     // ---- geometry (the same for every k-step). align_corners=True: src = dst * (in-1)/(out-1), as lerp_coord() of resample.hip
     const float ys = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, xs = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const int sy0 = min((int)(ys * (float)max(y0 - 1, 0)), h - 1), sx0 = min((int)(xs * (float)max(x0 - 1, 0)), w - 1);
     int ia[NI], ib[NI];                         // LDS offsets of the four corners (16 bits each)
     float wxs[NI], wys[NI];
+    // Entry k of these arrays is item k in waves 0..3 and item k - 1 (mod 3) in waves 4..7: the interpolation slots of a k-step are
+    // I M I M I M in the early waves and M I M I M I in the late ones (below), and with the late waves' entries rotated every slot
+    // uses ONE entry index in both - a select between two entries per slot (round 3) made hipcc keep the arrays in scratch memory and
+    // reload 5 dwords per slot (vector-memory loads whose waits, vmcnt being in order, also drained the step's LDS-DMA: the weights of
+    // the NEXT step had to land before the running step's interpolation could go on).
+    const bool early = wave < 4;
 #pragma unroll
     for (int k = 0; k < NI; ++k) {
-        const int item = tid + NT * k;
+        const int item = tid + NT * (early ? k : (k + NI - 1) % NI);
         const int q = item >> 1, c = item & 1;
         const int py = q / PW, pxx = q - py * PW;
         const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
@@ -107,16 +122,24 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
             if (NP_W % 8 != 0 && wave + 8 * j >= NP_W) break;                       // wave-uniform
             const int piece = wave + 8 * j;
             const int co = min((piece % CB) * 32 + lr, N - 1);                       // couts >= N read row N - 1: never stored
-            glds16(wt + (unsigned)(co * (9 * C) + (piece / CB) * C + step * KC + w_lane), buf + piece * 1024);
+            glds16_opaque(wt + (unsigned)(co * (9 * C) + (piece / CB) * C + step * KC + w_lane), buf + piece * 1024);
         }
     };
     auto stage_src = [&](int step, char* buf) {
-        if (wave < NP_SRC) glds16(in + (unsigned)(src_goff + step * KC), buf + wave * 1024);
+        if (wave < NP_SRC) glds16_opaque(in + (unsigned)(src_goff + step * KC), buf + wave * 1024);
     };
     // one (patch pixel, chunk) item: out = a00*(1-wx)(1-wy) + a01*wx(1-wy) + a10*(1-wx)wy + a11*wx*wy in fp32 (four v_fma_mix per
     // channel), one rounding to fp16. Branch-free: items past the patch write into its padding rows, pixels outside the image
     // write zeros (the conv's padding).
-    auto interp_item = [&](int k, int iav, int ibv, float wx, float wy, const char* sb, char* pb) {
+    // where an item lands in the patch image: the same in every k-step. Items past the patch (the last 312 threads' third item) land
+    // in the patch buffer's 28 padding rows
+    int woff[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int item = tid + NT * (early ? k : (k + NI - 1) % NI), q = item < NITEM ? item >> 1 : NPIX + (lane & 15);
+        woff[k] = patch_off(q, item & 1);
+    }
+    auto interp_item = [&](int wo, int iav, int ibv, float wx, float wy, const char* sb, char* pb) {
         const h16x8 a00 = *reinterpret_cast<const h16x8*>(sb + (iav & 0xffff)), a01 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)iav >> 16));
         const h16x8 a10 = *reinterpret_cast<const h16x8*>(sb + (ibv & 0xffff)), a11 = *reinterpret_cast<const h16x8*>(sb + ((unsigned)ibv >> 16));
         const float ux = 1.f - wx, uy = 1.f - wy;
@@ -124,14 +147,11 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
         h16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (h16)((float)a00[e] * w00 + (float)a01[e] * w01 + (float)a10[e] * w10 + (float)a11[e] * w11);
-        // items past the patch (the last 312 threads' third item) land in the patch buffer's 28 padding rows
-        const int item = tid + NT * k, q = item < NITEM ? item >> 1 : NPIX + (lane & 15);
-        *reinterpret_cast<h16x8*>(pb + lds_off(q, item & 1)) = o;
+        *reinterpret_cast<h16x8*>(pb + wo) = o;
     };
-    auto interp = [&](int k, const char* sb, char* pb) { interp_item(k, ia[k], ib[k], wxs[k], wys[k], sb, pb); };
-    // item ka in the early waves, item kb in the late ones (wave-uniform select between two register sets)
-    auto interp_sel = [&](bool early, int ka, int kb, const char* sb, char* pb) {
-        interp_item(early ? ka : kb, early ? ia[ka] : ia[kb], early ? ib[ka] : ib[kb], early ? wxs[ka] : wxs[kb], early ? wys[ka] : wys[kb], sb, pb);
+    auto interp = [&](int k, const char* sb, char* pb) {
+        if constexpr (DBG == 1) return;                        // TIMING EXPERIMENT 1 (results invalid): no interpolation
+        interp_item(woff[k], ia[k], ib[k], wxs[k], wys[k], sb, pb);
     };
 
     f32x16 acc[2][CB];
@@ -159,16 +179,21 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     // A kx group's 6 CB MFMAs are one scheduling region (the next 32-cout block's weight fragments are requested before the running
     // block's six MFMAs). The three interpolation items sit BETWEEN the groups, one slot earlier in waves 0..3 than in waves 4..7
     // (I M I M I M against M I M I M I): waves w and w + 4 share a SIMD, so one partner's VALU phase runs under the other's MFMAs.
-    const bool early = wave < 4;
+    // fragment addresses: lane constants (one per kx for the patch, one for the weights) + immediates
+    int pbase[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) pbase[kx] = (wave * 2 * PW + px + kx) * ROWB + ((hh ^ (((px + kx) >> 3) & 1)) << 4);
+    const int wbase = lds_off(px, hh);
     auto mfma_group = [&](int kx, const char* pc, const char* wc) {
+        if constexpr (DBG == 2) return;                        // TIMING EXPERIMENT 2 (results invalid): no MFMA groups
         h16x8 P[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) P[i] = *reinterpret_cast<const h16x8*>(pc + lds_off((wave * 2 + i) * PW + px + kx, hh));
+        for (int i = 0; i < 4; ++i) P[i] = *reinterpret_cast<const h16x8*>(pc + pbase[kx] + i * PW * ROWB);
         h16x8 Wf[CB][3];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) Wf[cb][ky] = *reinterpret_cast<const h16x8*>(wc + lds_off(((ky * 3 + kx) * CB + cb) * 32 + px, hh));
+            for (int ky = 0; ky < 3; ++ky) Wf[cb][ky] = *reinterpret_cast<const h16x8*>(wc + wbase + ((ky * 3 + kx) * CB + cb) * 32 * ROWB);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -196,13 +221,13 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
         if (early) interp(0, sb, pb);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(0, pc, wc);
-        interp_sel(early, 1, 0, sb, pb);
+        interp(1, sb, pb);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(1, pc, wc);
-        interp_sel(early, 2, 1, sb, pb);
+        interp(2, sb, pb);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group(2, pc, wc);
-        if (!early) interp(2, sb, pb);
+        if (!early) interp(0, sb, pb);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this step's LDS-DMA landed before the barrier publishes it
         __syncthreads();
     }
@@ -214,6 +239,49 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     static_assert(NI == 3, "the interpolation items ride on the three kx groups");
 
     // ---- epilogue: lane = pixel (lane & 31) of row r; registers 4g..4g+3 of block cb = channels cb*32 + 8g + 4hh .. +3
+    // [r4] WIDE form (N, ldc multiples of 8, out 16-byte aligned: every shape the model runs): the two lanes of a pixel (hh = 0 / 1)
+    // hold the interleaved 4-channel groups 8g + 4hh of a 32-channel block; one v_permlane32_swap per register hands the lower lane
+    // channels 0..15 and the upper lane 16..31, and each lane stores 2 x 16 bytes instead of 4 x 8: half the store instructions and
+    // no 8-byte fragments for L2 to merge (the 8-byte form wrote 851 MB for 718 MB of output, profiles/r03).
+    if (wide) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = y0 + wave * 2 + r, ox = x0 + px;
+            const bool inb = oy < H && ox < W;                  // (the swaps below run on every lane)
+            const size_t row = ((size_t)(b * H + min(oy, H - 1)) * W + min(ox, W - 1)) * ldc;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                unsigned pk[4][2];                              // channel groups g = 0..3 as packed fp16 pairs
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = cb * 32 + 8 * g + 4 * hh;
+                    f32x4 v = {acc[r][cb][4 * g], acc[r][cb][4 * g + 1], acc[r][cb][4 * g + 2], acc[r][cb][4 * g + 3]};
+                    if (bias && n < N) v += *reinterpret_cast<const f32x4*>(bias + n);
+                    const h16x4 o = {(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]};
+                    pk[g][0] = reinterpret_cast<const unsigned*>(&o)[0];
+                    pk[g][1] = reinterpret_cast<const unsigned*>(&o)[1];
+                }
+                // A = groups 0, 1; B = groups 2, 3: the upper lanes' A goes to the lower lanes' B and back
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(pk[g][e], pk[g + 2][e], false, false);
+                        pk[g][e] = sw[0];
+                        pk[g + 2][e] = sw[1];
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                   // lower lane: channels 8j..8j+7 of the block, upper lane: 16 + 8j ..
+                    const int n = cb * 32 + 16 * hh + 8 * j;
+                    if (inb && n < N) {
+                        const uint4 o = {pk[j][0], pk[j][1], pk[j + 2][0], pk[j + 2][1]};
+                        *reinterpret_cast<uint4*>(out + row + n) = o;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int oy = y0 + wave * 2 + r, ox = x0 + px;
@@ -233,22 +301,28 @@ __global__ void __launch_bounds__(NT) conv3x3_up2_kernel(const h16* __restrict__
     }
 }
 
-template <int CB>
+static int g_up2_variant = 0;
+template <int CB, int DBG = 0>
 int launch_up2(const h16* in, const h16* wt, const float* bias, h16* out, int B, int h, int w, int C, int N, int ldc, hipStream_t s) {
     constexpr int smem = 2 * (9 * CB * 1024 + PATCH_BYTES + SRC_BYTES);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static VdaKernelDeviceState dev_state;
-    if (vda_prepare_kernel(reinterpret_cast<const void*>(&conv3x3_up2_kernel<CB>), smem, dev_state) < 0) return 2;
+    if (vda_prepare_kernel(reinterpret_cast<const void*>(&conv3x3_up2_kernel<CB, DBG>), smem, dev_state) < 0) return 2;
     const int tiles_x = (2 * w + TW - 1) / TW, tiles_y = (2 * h + TH - 1) / TH;
     const long long ntiles = (long long)tiles_x * tiles_y * B;
     VDA_REQUIRE(ntiles < (1ll << 30), "vda_conv3x3_up2: too many tiles");
-    hipLaunchKernelGGL((conv3x3_up2_kernel<CB>), dim3((unsigned)((ntiles + 7) / 8 * 8)), dim3(NT), smem, s, in, wt, bias, out, h, w, C, N, ldc,
+    hipLaunchKernelGGL((conv3x3_up2_kernel<CB, DBG>), dim3((unsigned)((ntiles + 7) / 8 * 8)), dim3(NT), smem, s, in, wt, bias, out, h, w, C, N, ldc,
                        tiles_x, tiles_y, (int)ntiles);
     VDA_LAUNCH_CHECK();
     return 0;
 }
 
 }  // namespace
+
+extern "C" int vda_conv3x3_up2_set_variant(int v) {
+    g_up2_variant = v;
+    return 0;
+}
 
 extern "C" int vda_conv3x3_up2_f16(const void* in, const void* w, const float* bias, void* out, int B, int h, int wd, int C, int N, int ldc,
                                    vda_stream_t stream) {
@@ -263,5 +337,7 @@ extern "C" int vda_conv3x3_up2_f16(const void* in, const void* w, const float* b
     const h16 *ip = (const h16*)in, *wp = (const h16*)w;
     if (N <= 32) return launch_up2<1>(ip, wp, bias, (h16*)out, B, h, wd, C, N, ldc, s);
     if (N <= 64) return launch_up2<2>(ip, wp, bias, (h16*)out, B, h, wd, C, N, ldc, s);
+    if (g_up2_variant == 1) return launch_up2<4, 1>(ip, wp, bias, (h16*)out, B, h, wd, C, N, ldc, s);      // timing experiments (tools/conv_up_variants.py)
+    if (g_up2_variant == 2) return launch_up2<4, 2>(ip, wp, bias, (h16*)out, B, h, wd, C, N, ldc, s);
     return launch_up2<4>(ip, wp, bias, (h16*)out, B, h, wd, C, N, ldc, s);
 }

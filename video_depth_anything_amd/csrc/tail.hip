@@ -265,14 +265,6 @@ constexpr int SMEM2 = 2 * W_PASS_BYTES + 2 * PATCH_BYTES2 + 2 * SRC_BYTES;      
 // addresses 2 (v1 recomputes ~4 VALU instructions per fragment and pass)
 __device__ __forceinline__ int swzc(int col) { return (col >> 2) & 3; }
 
-// LDS-DMA as opaque assembly: with the builtin (glds16) hipcc's waitcnt pass guards every later ds_read of the wave with vmcnt(0) - it
-// cannot tell the DMA's destination from the buffers the interpolation reads - which would put the DMA's whole latency in front of the
-// interpolation. The fill waves wait for their DMA themselves, once, before the barrier that publishes it.
-__device__ __forceinline__ void glds16_opaque(const void* gsrc, void* lds_base) {
-    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_base);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
-}
-
 // the source rows / columns a 16 x 32 tile's patch can touch, exactly as the kernel computes them (host side: sizes the source region)
 inline int src_extent(float scale, int tile, int halo_lo, int out_n, int in_n) {
     int ext = 1;
@@ -433,6 +425,11 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bar();
+        if constexpr (DBG >= 4) {                              // TIMING EXPERIMENTS 4..6: the MFMA side alone
+            for (int u = 0; u < nu; ++u)
+                if (DBG != 6) bar();
+            return;
+        }
         for (int u = 0; u < nu; ++u) {
             // patch of unit u + 1 from source[(u + 1) & 1] (landed before the barrier behind us)
             // first the DMA - weights of unit u + 1 (its ring slot was last read in unit u - 1), source of unit u + 2 into the region
@@ -497,11 +494,11 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
         load_frag(0, pc, wc, f[0]);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            if (g + 1 < 6) {
+            if (g + 1 < 6 && DBG != 5) {
                 load_frag(g + 1, pc, wc, f[(g + 1) & 1]);
                 __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);      // the next group's fragments are requested first ...
             }
-            mma(f[g & 1]);
+            mma(f[DBG == 5 ? 0 : g & 1]);                               // (experiment 5: no fragment reads but the first group's)
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);          // ... then this group's six MFMAs
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -513,7 +510,7 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
     for (int k = 0; k < nmy; ++k) {
         for (int pass = 0; pass + 1 < npass; ++pass) {
             unit();
-            bar();
+            if (DBG != 6) bar();
         }
         unit();
         {
@@ -535,7 +532,7 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
             }
         }
         tile += per_xcd;
-        bar();
+        if (DBG != 6) bar();
     }
 }
 }  // namespace v2
@@ -568,9 +565,12 @@ extern "C" int vda_depth_tail_f16(const void* in, const void* w2, const float* b
         const int tx2 = (W + v2::TW2 - 1) / v2::TW2, ty2 = (H + v2::TH2 - 1) / v2::TH2;
         const long long nt2 = (long long)tx2 * ty2 * B;
         VDA_REQUIRE(nt2 < (1ll << 30), "vda_depth_tail: too many tiles");
-        static VdaKernelDeviceState dev_state[4];
-        const int dbg = (g_tail_variant >> 4) & 3;
-        auto* const fn = dbg == 1 ? &v2::depth_tail_up_kernel<1> : dbg == 2 ? &v2::depth_tail_up_kernel<2> : dbg == 3 ? &v2::depth_tail_up_kernel<3> : &v2::depth_tail_up_kernel<0>;
+        static VdaKernelDeviceState dev_state[8];
+        const int dbg = (g_tail_variant >> 4) & 7;              // timing experiments (results invalid), tools/tail_variants.py
+        using KFn = void (*)(const h16*, const h16*, const float*, const float*, float, float*, int, int, int, int, int, int, int, int, float, float, int, int);
+        static const KFn fns[8] = {&v2::depth_tail_up_kernel<0>, &v2::depth_tail_up_kernel<1>, &v2::depth_tail_up_kernel<2>, &v2::depth_tail_up_kernel<3>,
+                                   &v2::depth_tail_up_kernel<4>, &v2::depth_tail_up_kernel<5>, &v2::depth_tail_up_kernel<6>, &v2::depth_tail_up_kernel<0>};
+        const KFn fn = fns[dbg];
         const int ncu = vda_prepare_kernel(reinterpret_cast<const void*>(fn), v2::SMEM2, dev_state[dbg]);
         if (ncu < 0) return 2;
         const int grid2 = (int)(nt2 < ncu ? (nt2 + 7) / 8 * 8 : ncu);

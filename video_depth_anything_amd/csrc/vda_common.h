@@ -150,6 +150,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
     __builtin_amdgcn_global_load_lds((const VDA_GLOBAL_AS void*)gsrc, (VDA_LDS_AS void*)lds_base, 16, 0, 0);
 }
 
+// LDS-DMA as opaque assembly: with the builtin (glds16) hipcc's waitcnt pass guards later ds_reads of the wave with vmcnt waits - it
+// cannot tell the DMA's destination from the LDS buffers being read - which puts the DMA's whole latency in front of whatever reads
+// LDS next (found in round 4: the depth tail's interpolation, and EVERY k-step of conv3x3_up2_kernel, whose fragment reads waited for
+// the weights of the NEXT step to land). Callers wait for their DMA themselves (s_waitcnt vmcnt) before the barrier that publishes it.
+__device__ __forceinline__ void glds16_opaque(const void* gsrc, void* lds_base) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(gsrc) : "memory", "m0");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
