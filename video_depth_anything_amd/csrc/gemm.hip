@@ -499,6 +499,37 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
                                                     : (a.N <= 64 ? "gemm_kernel<128, 64, 1>" : "gemm_kernel<128, 128, 1>");
             return launch_small(a, s);
         }
+        // N a multiple of 384 (ViT-S's embedding width: proj / fc2 N = 384, qkv N = 1152): 192 x 384 tiles on twelve waves, one tile
+        // per row panel and column third - A and the residual rows are read once, 229 row panels are one round of the chip.
+        // Built, tested (variant 10) and NOT the default (VDA_GEMM_BN384=1 enables it): in-process A/B (tools/gemm_ab.py
+        // AB_SHAPES=vits -1,3,8,10, round 3) it wins with a plain epilogue (fc2's shape 70.7 -> 52.4 us) and not with the ones the
+        // model uses - split residual: fc2 80.0 -> 79.6, proj 38.2 -> 43.2 us; qkv + LayerNorm 61.5 -> 64.1 - and the ViT-S forward is
+        // 8.86 -> 9.15 ms with it: a single round puts every CU's residual epilogue (270 MB for fc2) on HBM at the same moment with no
+        // K loop anywhere to hide behind.
+        // [r4] The split-residual instantiation had been reloading two K-loop registers from scratch in every K tile (168 VGPRs; a
+        // scratch reload is a vector-memory load whose in-order wait drains the tile's LDS-DMA) and spilling 76 registers around its
+        // epilogue. With the epilogue's lane-derived addresses kept out of the K loop's live set and half-size row groups (gemm256s_kernel.h)
+        // fc2's shape is 86.9 -> 69.5 us with the split residual and 82.1 -> 63.0 with the fp32 one, proj's is a tie (41.6 / 41.4),
+        // and with the LayerNorm-folded epilogues it now wins on qkv (N = 1152: 60.4 -> 55.5 us) and fc1 (N = 1536, against the 8-phase
+        // 256 x 256 tile: 107.0 -> 91.1 us) (profiles/r04/vits_bn384_ab.txt). DEFAULT (VDA_GEMM_BN384 unset or 2): N = 384 with
+        // K >= 1024 (ViT-S's fc2, any built epilogue) and N <= 1536 with a LayerNorm-folded epilogue (ViT-S's qkv and fc1);
+        // 1 = every N % 384 == 0 up to 1152, 0 = never.
+        static const int wide384 = getenv("VDA_GEMM_BN384") ? atoi(getenv("VDA_GEMM_BN384")) : 2;
+        const bool ln_epi = a.epilogue == VDA_EPI_LN_BIAS_F16 || a.epilogue == VDA_EPI_LN_GELU_F16;
+        const bool auto384 = g_gemm_variant < 0 && a.tile_rows == 0 &&
+                             (wide384 == 1 ? (!eight && a.N <= 1152)
+                                            : wide384 == 2 ? ((a.N == 384 && a.K >= 1024) || (ln_epi && a.N <= 1536))
+                                            : wide384 == 3 ? (a.N == 384 && a.K >= 1024)                                     // (A/B: fc2 only)
+                                            : wide384 == 4 ? ((a.N == 384 && a.K >= 1024) || (ln_epi && a.N == 1536)) : false);   // (A/B: fc2 + fc1)
+        if (a.a_mode == VDA_A_DENSE && a.N % 384 == 0 && (auto384 || g_gemm_variant == 10)) {
+            const int rc384 = vda_gemm256s_dense_bn384_bm192(a8, s);
+            if (rc384 >= 0) {
+                static thread_local char name384[64];
+                snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192, 1>", a.a_mode, a.epilogue);
+                g_last_kernel = name384;
+                return rc384;
+            }
+        }
         // Row split (vda_gemm_plan_split): whole rounds of 256-row tiles + one launch of 192-row tiles for the remainder. Applied here
         // when the caller left it to the dispatcher (no per-launch sched counters: those belong to ONE launch).
         if (eight && big == 256 && a.a_mode == VDA_A_DENSE && g_gemm_variant < 0 && may_split && a.tile_rows == 0 && a.sched == nullptr && a.lda != 0) {
@@ -518,23 +549,6 @@ static int vda_gemm_f16_impl(const vda_gemm_args* args, vda_stream_t stream, boo
                 snprintf(name192, sizeof(name192), "gemm8p_kernel<256, %d, %d, 1, 192, %s>", a.a_mode, a.epilogue, a.sched ? "true" : "false");
                 g_last_kernel = name192;
                 return rc192;
-            }
-        }
-        // N a multiple of 384 (ViT-S's embedding width: proj / fc2 N = 384, qkv N = 1152): 192 x 384 tiles on twelve waves, one tile
-        // per row panel and column third - A and the residual rows are read once, 229 row panels are one round of the chip.
-        // Built, tested (variant 10) and NOT the default (VDA_GEMM_BN384=1 enables it): in-process A/B (tools/gemm_ab.py
-        // AB_SHAPES=vits -1,3,8,10, round 3) it wins with a plain epilogue (fc2's shape 70.7 -> 52.4 us) and not with the ones the
-        // model uses - split residual: fc2 80.0 -> 79.6, proj 38.2 -> 43.2 us; qkv + LayerNorm 61.5 -> 64.1 - and the ViT-S forward is
-        // 8.86 -> 9.15 ms with it: a single round puts every CU's residual epilogue (270 MB for fc2) on HBM at the same moment with no
-        // K loop anywhere to hide behind.
-        static const int wide384 = getenv("VDA_GEMM_BN384") ? atoi(getenv("VDA_GEMM_BN384")) : 0;
-        if (a.a_mode == VDA_A_DENSE && a.N % 384 == 0 && ((g_gemm_variant < 0 && wide384 && !eight && a.N <= 1152) || g_gemm_variant == 10)) {
-            const int rc384 = vda_gemm256s_dense_bn384_bm192(a8, s);
-            if (rc384 >= 0) {
-                static thread_local char name384[64];
-                snprintf(name384, sizeof(name384), "gemm256s_kernel<384, %d, %d, 192, 1>", a.a_mode, a.epilogue);
-                g_last_kernel = name384;
-                return rc384;
             }
         }
         if (g_gemm_variant == 11 && a.a_mode == VDA_A_DENSE) {        // 192 x 128, two workgroups per CU (A/B only, see gemm256s_kernel.h)

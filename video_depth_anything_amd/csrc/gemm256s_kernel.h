@@ -280,13 +280,21 @@ __global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kerne
             using RT = vda_gemm::RowTraits<EPI>;
             constexpr int NC = RT::NC, RR = RT::f32_out ? 8 : 4;            // columns per lane, row groups per 32-row block
             // lane -> (row inside a group, column block): fp32 out: 4 rows x 16 lanes x 4 cols; fp16 out: 8 rows x 8 lanes x 8 cols
-            const int lrow_e = RT::f32_out ? (lane >> 4) : (lane >> 3);
-            const int c0 = RT::f32_out ? (lane & 15) : 2 * (lane & 7);      // first 16-byte (4-column) chunk of the lane
+            // (twelve-wave tile, 168 VGPRs: the epilogue's lane-derived offsets are recomputed here from an opaque copy of the lane id,
+            // so that hipcc cannot hoist them - and the 64-bit addresses built on them - above the tile loop and keep them live, i.e.
+            // spilled, across the K loop: the split-residual instantiation reloaded two of its K-loop registers from scratch in EVERY K
+            // tile, and a scratch reload is a vector-memory load whose in-order wait also drains the tile's LDS-DMA)
+            int lane_e = lane;
+            if constexpr (BN == 384) asm volatile("" : "+v"(lane_e));
+            const int lrow_e = RT::f32_out ? (lane_e >> 4) : (lane_e >> 3);
+            const int c0 = RT::f32_out ? (lane_e & 15) : 2 * (lane_e & 7);      // first 16-byte (4-column) chunk of the lane
             const int en = bn0 + c0 * 4;
             const bool geglu_idle = (EPI == VDA_EPI_GEGLU_F16) && (c0 & 7) >= 4;   // gate lanes only feed their value lanes
             vda_gemm::ColConst<NC> cc;
             vda_gemm::load_col_const<EPI, NC>(p, en, cc);
-            constexpr int RG = RT::f32_out ? 4 : 2;                          // rows per row group
+            // rows per row group (twelve-wave tile: half as many - three RowAux sets instead of six are live at the first block, where
+            // all 96 accumulators still are; twelve waves per CU keep as many row loads in flight as eight did)
+            constexpr int RG = RT::f32_out ? (BN == 384 ? 2 : 4) : (BN == 384 ? 1 : 2);
             vda_gemm::RowAux carry[RG];                                      // the next block's first group, loaded a group early
 #pragma unroll
             for (int i = 0; i < MI / 2; ++i) {
@@ -295,7 +303,7 @@ __global__ void __launch_bounds__(BN == 384 ? 768 : BM / 32 * 64) gemm256s_kerne
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         // accumulator (mi = 2i+h2, nj = j): row = h2*16 + (lane & 15) of the 32-row block, columns 16j + 4*(lane>>4) + e
-                        const int row = h2 * 16 + (lane & 15), c = j * 4 + (lane >> 4);
+                        const int row = h2 * 16 + (lane_e & 15), c = j * 4 + (lane_e >> 4);
                         *reinterpret_cast<f32x4*>(stg + row * 256 + ((c ^ (row & 15)) << 4)) = acc[2 * i + h2][j];
                     }
                 // The transposition is a cross-LANE exchange inside one wave: the hardware runs a wave's LDS ops in order,
