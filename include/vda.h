@@ -284,6 +284,9 @@ int vda_conv3x3_up2_f16(const void* in, const void* w, const float* bias, void* 
                         vda_stream_t stream);
 /* Timing experiments of the fused kernel at N > 64 (results invalid): 1 = no interpolation, 2 = no MFMA groups; 0 = the kernel. */
 int vda_conv3x3_up2_set_variant(int v);
+/* The LDS-patch 3x3 convolution behind vda_gemm_f16 (N <= 64, stride 1): 0 (default) = the persistent C = 64 kernel where it applies,
+ * 1 = the per-pass kernel for every shape. Bit-identical results; A/B only. */
+int vda_conv_lds_set_variant(int v);
 
 /* uint8 RGB frames [n,H,W,3] (already at network size) -> normalised fp32 NCHW
  * [n,3,H,W]: (x/255 - mean)/std  (video_depth.py:198, util/transform.py:134,147). */

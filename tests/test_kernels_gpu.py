@@ -195,6 +195,36 @@ def test_conv3x3(ops, gemm_variant, stride, relu_in, Cin, Cout, H, W_):
     close(out, ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W_,Cout,epi,relu_in,two_res", [(3, 9, 11, 64, "res", True, True), (2, 20, 37, 32, "bias", False, False), (1, 83, 79, 64, "relu", True, False),
+                                                            (2, 45, 70, 24, "res", False, False), (32, 74, 74, 64, "res", True, True), (8, 148, 148, 64, "relu", True, False)])
+def test_conv3x3_c64_persistent_equals_per_pass_kernel(ops, B, H, W_, Cout, epi, relu_in, two_res):
+    """The persistent 64-input-channel LDS convolution (resident weights, specialised waves, two patch buffers; the last two cases have more
+    tiles than workgroups) against the per-pass kernel it replaces: the same MFMA order per output element, so bit-identical."""
+    from video_depth_anything_amd import _lib
+    Cin = 64
+    x = dev(rnd(B, H, W_, Cin, seed=401).to(F16))
+    w, b = dev(ops.pack_conv3x3(rnd(Cout, Cin, 3, 3, seed=402, scale=(9 * Cin) ** -0.5))), dev(rnd(Cout, seed=403))
+    res = dev(rnd(B, H, W_, Cout, seed=404).to(F16))
+    res2 = dev(rnd(B, H, W_, Cout, seed=405).to(F16))
+    e = {"res": _lib.EPI_RES_F16, "bias": _lib.EPI_BIAS_F16, "relu": _lib.EPI_BIAS_RELU_F16}[epi]
+    kw = dict(M=B * H * W_, N=Cout, K=9 * Cin, bias=b, relu_in=relu_in, conv=(B, H, W_, Cin, H, W_, 1))
+    if epi == "res":
+        kw.update(res=res)
+        if two_res:
+            kw.update(res2=res2)
+    outs = []
+    try:
+        for v in (1, 0):
+            _lib.lib.vda_conv_lds_set_variant(v)
+            out = torch.full((B, H, W_, Cout), float("nan"), dtype=F16, device="cuda")
+            ops.gemm(x, w, out, e, **kw)
+            outs.append(out)
+    finally:
+        _lib.lib.vda_conv_lds_set_variant(0)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 # ---------------------------------------------------------------- LayerNorm folded into the GEMMs either side of it
 def split_planes(x):
     hi = x.to(F16)

@@ -69,6 +69,7 @@ SIGNATURES = {
     "vda_attention_set_variant": (_i, [_i]),
     "vda_depth_tail_set_variant": (_i, [_i]),
     "vda_conv3x3_up2_set_variant": (_i, [_i]),
+    "vda_conv_lds_set_variant": (_i, [_i]),
     "vda_temporal_attention_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_temporal_attention_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "vda_temporal_attention_set_variant": (_i, [_i]),
