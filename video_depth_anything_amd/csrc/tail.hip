@@ -290,6 +290,8 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int npass = C / CC;
+    const bool tail_prio = (SH >> 16) == 0;                    // (A/B switch riding on an argument's unused upper half: set = off)
+    SH &= 0xffff;
     // the XCD's contiguous share of the tiles, dealt to its workgroups tile by tile: the workgroups of an XCD work on neighbouring tiles
     // at any moment (shared halo and source pixels in that XCD's L2)
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -312,6 +314,10 @@ __global__ void __launch_bounds__(NT2) depth_tail_up_kernel(const h16* __restric
 
     if (wave >= MMA_WAVES) {
         // =================================================== fill waves ===================================================
+        // The fill waves go AHEAD of the MFMA waves at the issue arbiter: they are the critical path to the barrier (their pass takes
+        // longer than the 36 MFMAs of an MFMA wave), and an MFMA wave loses nothing by yielding an issue slot while its matrix pipe is
+        // busy. 773 -> 740 us in one process (priority 2: 796 -> 772; the MFMA waves ahead instead: 777 -> 799). Variant bit 3 = off (A/B).
+        if (tail_prio) __builtin_amdgcn_s_setprio(3);
         const int fw = wave - MMA_WAVES;                       // 0..7
         const int ft = tid - MMA_WAVES * 64;                   // 0..511
         const int ch = ft & 3, lr = lane >> 2;
@@ -561,7 +567,7 @@ extern "C" int vda_depth_tail_f16(const void* in, const void* w2, const float* b
     // v2: persistent, specialised waves, source region staged in LDS (tools/tail_bench.py; variant 1 = v1 for A/B). Needs the region
     // under a 18 x 34 patch to fit 256 pixels - any upsampling by >= ~1.3 does (1.75 everywhere in the product)
     const int SH = v2::src_extent(ys, v2::TH2, -1, H, h), SW = v2::src_extent(xs, v2::TW2, -1, W, w);
-    if ((h != H || w != W) && SH * SW <= v2::SRC_ROWS && (g_tail_variant & 15) != 1) {
+    if ((h != H || w != W) && SH * SW <= v2::SRC_ROWS && (g_tail_variant & 7) != 1) {
         const int tx2 = (W + v2::TW2 - 1) / v2::TW2, ty2 = (H + v2::TH2 - 1) / v2::TH2;
         const long long nt2 = (long long)tx2 * ty2 * B;
         VDA_REQUIRE(nt2 < (1ll << 30), "vda_depth_tail: too many tiles");
@@ -575,7 +581,7 @@ extern "C" int vda_depth_tail_f16(const void* in, const void* w2, const float* b
         if (ncu < 0) return 2;
         const int grid2 = (int)(nt2 < ncu ? (nt2 + 7) / 8 * 8 : ncu);
         hipLaunchKernelGGL(fn, dim3(grid2), dim3(v2::NT2), v2::SMEM2, s, (const h16*)in, (const h16*)w2, b2, w3, b3, out, h, w, H, W, C,
-                           tx2, ty2, (int)nt2, ys, xs, SH, SW);
+                           tx2, ty2, (int)nt2, ys, xs, SH | ((g_tail_variant & 8) ? 1 << 16 : 0), SW);
         VDA_LAUNCH_CHECK();
         return 0;
     }
